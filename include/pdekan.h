@@ -1,0 +1,120 @@
+/* pdekan - C ABI of the MI355X (gfx950) KAN layer / Black-Scholes PINN step.
+ *
+ * The reference (iqq-0906/PDE) has no native interface for this path: its only
+ * boundary is the Python module `efficient_kan` (efficient_kan/__init__.py:1-3)
+ * whose `KANLinear.forward` / `KAN.forward` (efficient_kan/kan.py:153-166,
+ * :274-279) are differentiated by PyTorch autograd inside the scripts'
+ * `residual_net` / `loss_res` (run1.py:120-149).  The entry points below are
+ * what a binding for that path has to call; each comment names the reference
+ * code it stands in for.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (fp32, contiguous
+ *     unless strides are passed).  The library allocates nothing: scratch comes
+ *     in through `ws` / `ws_bytes` (query the *_workspace_bytes function first;
+ *     256-byte aligned).
+ *   - `stream` is a hipStream_t (NULL = default stream).  Kernels are enqueued
+ *     asynchronously; no call synchronises.
+ *   - Return value 0 = ok, negative = error; text via pdekan_last_error()
+ *     (thread-local).  Nothing throws across the ABI.
+ *   - A "jet" of a scalar is J = 1 + n_dir + n_second floats:
+ *       [0] value, [1..n_dir] d/dx_d, [1+n_dir ..] d2/dx_d^2 for d < n_second.
+ *     Jet tensors are laid out [N][features][J].  Supported (n_dir, n_second):
+ *     (0,0) plain values, (2,1) one asset + time, (6,5) five assets + time.
+ *   - spline_order must be 3 (every caller in the reference uses the default).
+ *   - act_kind: 0 = identity (run1.py:478-482 pass nn.Identity), 1 = SiLU
+ *     (module default, kan.py:17).
+ */
+#ifndef PDEKAN_H
+#define PDEKAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEKAN_OK 0
+#define PDEKAN_ERR_ARG (-1)        /* bad shape / unsupported combination */
+#define PDEKAN_ERR_WORKSPACE (-2)  /* ws too small or misaligned */
+#define PDEKAN_ERR_HIP (-3)        /* a HIP call failed */
+
+#define PDEKAN_ACT_IDENTITY 0
+#define PDEKAN_ACT_SILU 1
+
+/* Parameters and buffers of one KANLinear (kan.py:27-45):
+ *   grid [in][grid_size+2*spline_order+1], base_weight [out][in],
+ *   spline_weight [out][in][grid_size+spline_order],
+ *   spline_scaler [out][in] or NULL (enable_standalone_scale_spline=False). */
+typedef struct PdekanLayer {
+  int32_t in_features;
+  int32_t out_features;
+  int32_t grid_size;
+  int32_t spline_order;
+  int32_t act_kind;
+  int32_t reserved;
+  const float* grid;
+  const float* base_weight;
+  const float* spline_weight;
+  const float* spline_scaler;
+} PdekanLayer;
+
+/* Where the gradients of one layer's parameters go (same shapes as the
+ * parameters; spline_scaler may be NULL when the layer has none). */
+typedef struct PdekanLayerGrad {
+  float* base_weight;
+  float* spline_weight;
+  float* spline_scaler;
+} PdekanLayerGrad;
+
+int pdekan_version(void);
+const char* pdekan_last_error(void);
+
+/* Seed the input jets of the first layer from points x[N][d] (element strides
+ * given, so the permuted view of run1.py:101-106 needs no copy):
+ * value = x, d/dx_d = 1 for feature d, second derivatives = 0. */
+int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t n, int32_t d,
+                     int32_t n_dir, int32_t n_second, float* jet, void* stream);
+
+/* KANLinear.forward (kan.py:153-166) on jets: y_jet[N][out][J] from
+ * x_jet[N][in][J].  With (n_dir, n_second) = (0,0) this is exactly the
+ * reference forward; otherwise the derivative slots carry what autograd /
+ * jacrev / hessian would give for d y / d x_d and d2 y / d x_d^2. */
+size_t pdekan_layer_workspace_bytes(const PdekanLayer* layer, int64_t n, int32_t n_dir, int32_t n_second);
+int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n,
+                         int32_t n_dir, int32_t n_second, void* ws, size_t ws_bytes, void* stream);
+
+/* What loss.backward() does through that forward (run1.py:225): given the
+ * cotangent gy_jet[N][out][J], write gx_jet[N][in][J] (skipped if NULL) and
+ * the parameter gradients (skipped if grads is NULL; added to the existing
+ * contents if accumulate != 0). */
+int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const float* gy_jet, int64_t n,
+                          int32_t n_dir, int32_t n_second, float* gx_jet, const PdekanLayerGrad* grads,
+                          int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* KAN.forward (kan.py:274-279) on jets for a whole stack: points x[N][d] ->
+ * out_jet[N][out_last][J] (operator_net + jacrev/hessian of run1.py:121-124 in
+ * one pass).  micro_batch = points processed at a time (0 = all at once). */
+size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers, int64_t n,
+                                    int32_t n_dir, int32_t n_second, int64_t micro_batch);
+int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const float* x, int64_t stride_n,
+                             int64_t stride_d, int64_t n, int32_t n_dir, int32_t n_second, float* out_jet,
+                             int64_t micro_batch, void* ws, size_t ws_bytes, void* stream);
+
+/* One physics-informed training step without the optimiser update: forward,
+ * Black-Scholes residual (run1.py:128; several assets: summed diagonal terms),
+ * loss = sum((res - target)^2) / n_global (run1.py:148; n_global = n on one
+ * GPU, the job-wide count on a shard) and every parameter gradient
+ * (run1.py:225).  x[N][d] has the asset prices first and time last; target may
+ * be NULL (zeros, run1.py:358); res_out (N floats) and loss_out (1 float) may
+ * be NULL.  The last model layer must have one output. */
+int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, int64_t stride_n,
+                   int64_t stride_d, const float* target, int64_t n, int64_t n_global, float sigma,
+                   float rate, float* loss_out, float* res_out, const PdekanLayerGrad* grads,
+                   int32_t accumulate, int64_t micro_batch, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEKAN_H */

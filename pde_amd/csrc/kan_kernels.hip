@@ -1,0 +1,559 @@
+// Streaming (non-MFMA) kernels of the KAN layer for gfx950: used for layers
+// whose contraction is too skinny to be a dense GEMM (first layer: few inputs;
+// head: one output) and as the general path for any shape.
+//
+// Layouts (all fp32, row-major, innermost last):
+//   jets    a[N][I][J], y[N][O][J]      J = 1 + D + D2   (see kan_math.h)
+//   knots   grid[I][nk]                 nk = G + 2*3 + 1 (kan.py:27-36)
+//   packed weights of one layer, C1 = G+3+1 columns per (o,i) edge:
+//     wp[O][I][C1] : c < C1-1 -> spline_weight*spline_scaler (kan.py:145-151),
+//                    c = C1-1 -> base_weight
+//     wt[I*C1][O]  : the transpose, k = i*C1 + c
+#include <hip/hip_runtime.h>
+#include "kan_math.h"
+#include "kan_launch.h"
+
+namespace pdekan {
+
+// One record per (point, input feature): everything phase 2 needs.
+struct __attribute__((aligned(16))) EdgeRec {
+  float b[4], d1[4], d2[4];   // bases and derivatives of the 4 live splines
+  float f0, f1, f2;           // base activation and derivatives
+  int c0;                     // first live spline index (may be out of range)
+};
+
+__device__ __forceinline__ void load_knots_to_lds(float* s_knots, const float* grid, int count) {
+  for (int t = threadIdx.x; t < count; t += blockDim.x) s_knots[t] = grid[t];
+}
+
+// --------------------------------------------------------------------------
+// pack: parameters -> wp / wt
+// --------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ base_w, const float* __restrict__ spline_w,
+                                    const float* __restrict__ scaler, float* __restrict__ wp,
+                                    float* __restrict__ wt, int I, int O, int C) {
+  const int C1 = C + 1;
+  const int total = O * I * C1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int c = t % C1;
+    const int oi = t / C1;
+    const int i = oi % I, o = oi / I;
+    float v;
+    if (c < C) {
+      v = spline_w[(size_t)oi * C + c];
+      if (scaler) v *= scaler[oi];
+    } else {
+      v = base_w[oi];
+    }
+    wp[t] = v;
+    wt[(size_t)(i * C1 + c) * O + o] = v;
+  }
+}
+
+// --------------------------------------------------------------------------
+// seed: points x[N][d] (any strides) -> input jets a[N][d][J]
+// --------------------------------------------------------------------------
+template <int D, int D2>
+__global__ void seed_jets_kernel(const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
+                                 float* __restrict__ a, int64_t N, int I) {
+  constexpr int J = 1 + D + D2;
+  const int64_t total = N * I;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / I;
+    const int i = (int)(t % I);
+    float* out = a + t * J;
+    out[0] = x[p * stride_n + i * stride_d];
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[1 + d] = (d == i) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int d = 0; d < D2; ++d) out[1 + D + d] = 0.0f;
+  }
+}
+
+// --------------------------------------------------------------------------
+// forward, any shape.  A block owns PT points.  Phase 1: one thread per
+// (point, input) evaluates the basis once and parks it in LDS.  Phase 2: one
+// thread per (point, output, i-slice) walks the inputs, gathers the 4+1 live
+// weights (coalesced over o through wt) and accumulates the output jet; the
+// NIC i-slices of one output sit in adjacent lanes and are summed by shuffles.
+// --------------------------------------------------------------------------
+template <int D, int D2>
+__global__ void __launch_bounds__(256)
+fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid,
+                   const float* __restrict__ wt, float* __restrict__ y,
+                   int64_t N, int I, int O, int G, int act, int PT, int NIC) {
+  constexpr int J = 1 + D + D2;
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);
+  float* s_jet = reinterpret_cast<float*>(recs + PT * I);
+  float* s_knots = s_jet + PT * I * J;
+  load_knots_to_lds(s_knots, grid, I * nk);
+  __syncthreads();
+
+  const int64_t p0 = (int64_t)blockIdx.x * PT;
+  const int npts = (int)((N - p0 < PT) ? (N - p0) : PT);
+
+  for (int pair = threadIdx.x; pair < npts * I; pair += blockDim.x) {
+    const int i = pair % I;
+    const float* src = a + (p0 * I + pair) * J;
+    float jet[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
+    Basis bs;
+    eval_basis<false>(s_knots + i * nk, nk, jet[0], bs);
+    const Act av = eval_act(act, jet[0]);
+    EdgeRec r;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { r.b[m] = bs.b[m]; r.d1[m] = bs.d1[m]; r.d2[m] = bs.d2[m]; }
+    r.f0 = av.f0; r.f1 = av.f1; r.f2 = av.f2; r.c0 = bs.c0;
+    recs[pair] = r;
+  }
+  __syncthreads();
+
+  const int items = npts * O * NIC;
+  const int rounds = (PT * O * NIC + blockDim.x - 1) / blockDim.x;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int t = rd * blockDim.x + threadIdx.x;
+    const bool live = t < items;
+    const int ic = t % NIC;
+    const int po = t / NIC;
+    const int o = po % O, p = po / O;
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.0f;
+    if (live) {
+      for (int i = ic; i < I; i += NIC) {
+        const EdgeRec r = recs[p * I + i];
+        const float* jet = s_jet + (p * I + i) * J;
+        const float* wcol = wt + (size_t)(i * C1) * O + o;
+        const float wb = wcol[(size_t)C * O];
+        float p0v = wb * r.f0, p1v = wb * r.f1, p2v = wb * r.f2;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = r.c0 + m;
+          if (c >= 0 && c < C) {
+            const float w = wcol[(size_t)c * O];
+            p0v += w * r.b[m]; p1v += w * r.d1[m]; p2v += w * r.d2[m];
+          }
+        }
+        jet_accumulate<D, D2>(acc, jet, p0v, p1v, p2v);
+      }
+    }
+    for (int off = NIC >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[j] += __shfl_xor(acc[j], off);
+    }
+    if (live && ic == 0) {
+      float* dst = y + ((p0 + p) * O + o) * J;
+#pragma unroll
+      for (int j = 0; j < J; ++j) dst[j] = acc[j];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// backward to the input jet, any shape.  One thread per (point, input):
+//   Gm[m][j] = sum_o w[o][i][c0+m] * gy[p][o][j]   (m = 4 live splines + base)
+// then the chain rule through B, B', B'', B''' (cubic: the fourth derivative
+// vanishes, so three derivative orders close the recursion).
+// --------------------------------------------------------------------------
+template <int D, int D2>
+__global__ void __launch_bounds__(256)
+bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
+                         const float* __restrict__ grid, const float* __restrict__ wp,
+                         float* __restrict__ ga, int64_t N, int I, int O, int G, int act) {
+  constexpr int J = 1 + D + D2;
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_knots = reinterpret_cast<float*>(smem);
+  load_knots_to_lds(s_knots, grid, I * nk);
+  __syncthreads();
+  const int64_t total = N * I;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / I;
+    const int i = (int)(t % I);
+    float jet[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) jet[j] = a[t * J + j];
+    Basis bs;
+    eval_basis<true>(s_knots + i * nk, nk, jet[0], bs);
+    const Act av = eval_act(act, jet[0]);
+    float Gm[5][J];
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int j = 0; j < J; ++j) Gm[m][j] = 0.0f;
+    bool ok[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ok[m] = (bs.c0 + m >= 0) && (bs.c0 + m < C);
+    const float* gyp = gy + p * O * J;
+    for (int o = 0; o < O; ++o) {
+      const float* w = wp + ((size_t)o * I + i) * C1;
+      float wm[5];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) wm[m] = ok[m] ? w[bs.c0 + m] : 0.0f;
+      wm[4] = w[C];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float g = gyp[o * J + j];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) Gm[m][j] += wm[m] * g;
+      }
+    }
+    float out[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) out[j] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const float e1 = (m < 4) ? bs.d1[m < 4 ? m : 0] : av.f1;
+      const float e2 = (m < 4) ? bs.d2[m < 4 ? m : 0] : av.f2;
+      const float e3 = (m < 4) ? bs.d3[m < 4 ? m : 0] : av.f3;
+      out[0] += Gm[m][0] * e1;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        out[0] += Gm[m][1 + d] * jet[1 + d] * e2;
+        out[1 + d] += Gm[m][1 + d] * e1;
+      }
+#pragma unroll
+      for (int d = 0; d < D2; ++d) {
+        const float gdd = Gm[m][1 + D + d];
+        out[0] += gdd * (jet[1 + d] * jet[1 + d] * e3 + jet[1 + D + d] * e2);
+        out[1 + d] += 2.0f * jet[1 + d] * gdd * e2;
+        out[1 + D + d] += gdd * e1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) ga[t * J + j] = out[j];
+  }
+}
+
+// --------------------------------------------------------------------------
+// backward to the packed weights, any shape.  grid = (i-tiles, o-tiles,
+// point chunks); a block owns a TI x TO tile of edges and one chunk of points
+// and keeps a private column of C1 partial sums per edge in LDS (no atomics:
+// the result is bitwise reproducible).  Points are taken PT at a time: phase 1
+// evaluates the basis once per (point, input of the tile), phase 2 lets every
+// edge thread fold those points in.  Output: part[chunk][O][I][C1].
+// --------------------------------------------------------------------------
+constexpr int kBwTI = 16, kBwTO = 16, kBwPT = 16;
+
+template <int D, int D2>
+__global__ void __launch_bounds__(256)
+bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
+                          const float* __restrict__ grid, float* __restrict__ part,
+                          int64_t N, int I, int O, int G, int act, int64_t chunk_pts) {
+  constexpr int J = 1 + D + D2;
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);                  // [kBwPT][kBwTI]
+  float* s_A = reinterpret_cast<float*>(recs + kBwPT * kBwTI);       // [kBwPT][kBwTI][3] jets folded
+  float* s_jet = s_A;                                                // alias name: input jets [PT][TI][J]
+  float* s_gy = s_jet + kBwPT * kBwTI * J;                           // [kBwPT][kBwTO][J]
+  float* s_knots = s_gy + kBwPT * kBwTO * J;                         // [kBwTI][nk]
+  float* s_acc = s_knots + kBwTI * nk;                               // [C][256]
+
+  const int i0 = blockIdx.x * kBwTI, o0 = blockIdx.y * kBwTO;
+  const int ti = threadIdx.x % kBwTI, to = threadIdx.x / kBwTI;
+  const int i = i0 + ti, o = o0 + to;
+  const bool edge_live = (i < I) && (o < O);
+
+  for (int t = threadIdx.x; t < kBwTI * nk; t += blockDim.x) {
+    const int fi = i0 + t / nk;
+    s_knots[t] = (fi < I) ? grid[fi * nk + t % nk] : 0.0f;
+  }
+  for (int c = 0; c < C; ++c) s_acc[c * 256 + threadIdx.x] = 0.0f;
+  float acc_base = 0.0f;
+  __syncthreads();
+
+  const int64_t pbeg = (int64_t)blockIdx.z * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  for (int64_t pb = pbeg; pb < pend; pb += kBwPT) {
+    const int npts = (int)((pend - pb < kBwPT) ? (pend - pb) : kBwPT);
+    // phase 1: thread (pp, ti) evaluates input i0+ti at point pb+pp
+    {
+      const int pp = threadIdx.x / kBwTI;        // 256 / 16 = 16 = kBwPT
+      const int fi = i0 + ti;
+      if (pp < npts && fi < I) {
+        const float* src = a + ((pb + pp) * I + fi) * J;
+        float jet[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[(pp * kBwTI + ti) * J + j] = jet[j]; }
+        Basis bs;
+        eval_basis<false>(s_knots + ti * nk, nk, jet[0], bs);
+        const Act av = eval_act(act, jet[0]);
+        EdgeRec r;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { r.b[m] = bs.b[m]; r.d1[m] = bs.d1[m]; r.d2[m] = bs.d2[m]; }
+        r.f0 = av.f0; r.f1 = av.f1; r.f2 = av.f2; r.c0 = bs.c0;
+        recs[pp * kBwTI + ti] = r;
+      }
+      // and stage the cotangents of the tile's outputs
+      const int go = o0 + ti;                      // reuse (pp, ti) as (point, output)
+      if (pp < npts && go < O) {
+        const float* src = gy + ((pb + pp) * O + go) * J;
+#pragma unroll
+        for (int j = 0; j < J; ++j) s_gy[(pp * kBwTO + ti) * J + j] = src[j];
+      }
+    }
+    __syncthreads();
+    if (edge_live) {
+      for (int pp = 0; pp < npts; ++pp) {
+        const EdgeRec r = recs[pp * kBwTI + ti];
+        float A0, A1, A2;
+        jet_pullback_coeffs<D, D2>(s_gy + (pp * kBwTO + to) * J, s_jet + (pp * kBwTI + ti) * J, A0, A1, A2);
+        acc_base += A0 * r.f0 + A1 * r.f1 + A2 * r.f2;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = r.c0 + m;
+          if (c >= 0 && c < C) s_acc[c * 256 + threadIdx.x] += A0 * r.b[m] + A1 * r.d1[m] + A2 * r.d2[m];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (edge_live) {
+    float* dst = part + (((size_t)blockIdx.z * O + o) * I + i) * C1;
+    for (int c = 0; c < C; ++c) dst[c] = s_acc[c * 256 + threadIdx.x];
+    dst[C] = acc_base;
+  }
+}
+
+// --------------------------------------------------------------------------
+// sum the per-chunk partials in chunk order and unpack to parameter gradients:
+//   g_base[o][i]      = gW[o][i][C]
+//   g_spline[o][i][c] = gW[o][i][c] * scaler[o][i]           (scaler present)
+//   g_scaler[o][i]    = sum_c gW[o][i][c] * spline_w[o][i][c]
+// accumulate != 0 adds to what the output buffers already hold.
+// --------------------------------------------------------------------------
+__global__ void reduce_unpack_kernel(const float* __restrict__ part, int nchunks,
+                                     const float* __restrict__ spline_w, const float* __restrict__ scaler,
+                                     float* __restrict__ g_base, float* __restrict__ g_spline,
+                                     float* __restrict__ g_scaler, int I, int O, int C, int accumulate) {
+  const int C1 = C + 1;
+  const int edges = O * I;
+  const size_t stride = (size_t)edges * C1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < edges; e += gridDim.x * blockDim.x) {
+    float gs = 0.0f;
+    const float sc = scaler ? scaler[e] : 1.0f;
+    for (int c = 0; c < C1; ++c) {
+      float s = 0.0f;
+      const float* src = part + (size_t)e * C1 + c;
+      for (int k = 0; k < nchunks; ++k) s += src[k * stride];
+      if (c < C) {
+        const float v = s * sc;
+        float* dst = g_spline + (size_t)e * C + c;
+        *dst = accumulate ? (*dst + v) : v;
+        gs += s * spline_w[(size_t)e * C + c];
+      } else {
+        g_base[e] = accumulate ? (g_base[e] + s) : s;
+      }
+    }
+    if (g_scaler) g_scaler[e] = accumulate ? (g_scaler[e] + gs) : gs;
+  }
+}
+
+// --------------------------------------------------------------------------
+// Black-Scholes residual of the scalar head's jet, its squared-error loss and
+// the cotangent of the head's jet (run1.py:128, :148).  Inputs x[N][d] with the
+// last column = time; D = d, D2 = d-1.
+//   res = V_t + r V - sum_j ( 0.5 sigma^2 x_j^2 V_jj + r x_j V_j )
+//   loss_part[block] = sum (res - target)^2 ; gy = 2 (res - target) / n_global * dres/dV*
+// --------------------------------------------------------------------------
+template <int D, int D2>
+__global__ void __launch_bounds__(256)
+bs_residual_kernel(const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
+                   const float* __restrict__ vjet, const float* __restrict__ target,
+                   float sigma, float rate, float inv_n, float* __restrict__ res_out,
+                   float* __restrict__ gy, float* __restrict__ loss_part, int64_t N) {
+  constexpr int J = 1 + D + D2;
+  static_assert(D2 == D - 1, "assets first, time last");
+  float local = 0.0f;
+  const float hs2 = 0.5f * sigma * sigma;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    float v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = vjet[p * J + j];
+    float xs[D2];
+#pragma unroll
+    for (int d = 0; d < D2; ++d) xs[d] = x[p * stride_n + d * stride_d];
+    float res = v[D] + rate * v[0];                 // V_t is direction D-1 -> slot 1+(D-1) = D
+#pragma unroll
+    for (int d = 0; d < D2; ++d) res = res - hs2 * xs[d] * xs[d] * v[1 + D + d] - rate * xs[d] * v[1 + d];
+    const float diff = res - (target ? target[p] : 0.0f);
+    local += diff * diff;
+    if (res_out) res_out[p] = res;
+    if (gy) {
+      const float g = 2.0f * diff * inv_n;
+      float* dst = gy + p * J;
+      dst[0] = g * rate;
+#pragma unroll
+      for (int d = 0; d < D2; ++d) { dst[1 + d] = -g * rate * xs[d]; dst[1 + D + d] = -g * hs2 * xs[d] * xs[d]; }
+      dst[D] = g;
+    }
+  }
+  // block reduction in a fixed order: lanes by shuffle, waves through LDS
+  __shared__ float s_w[4];
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void loss_finish_kernel(const float* __restrict__ loss_part, int nparts, float inv_n,
+                                   float* __restrict__ loss_out, int accumulate) {
+  __shared__ float s_w[4];
+  float local = 0.0f;
+  for (int t = threadIdx.x; t < nparts; t += blockDim.x) local += loss_part[t];
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
+    *loss_out = accumulate ? (*loss_out + v) : v;
+  }
+}
+
+// --------------------------------------------------------------------------
+// host-side launchers
+// --------------------------------------------------------------------------
+static inline int pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
+
+void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st) {
+  const int total = L.O * L.I * (L.C() + 1);
+  const int blocks = (total + 255) / 256;
+  pack_weights_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(L.base_w, L.spline_w, L.scaler, wp, wt,
+                                                                  L.I, L.O, L.C());
+}
+
+template <int D, int D2>
+static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, int I, hipStream_t st) {
+  const int64_t total = N * I;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  seed_jets_kernel<D, D2><<<(int)blocks, 256, 0, st>>>(x, sn, sd, a, N, I);
+}
+
+template <int D, int D2>
+static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
+  constexpr int J = 1 + D + D2;
+  int PT = 256 / L.I; if (PT < 1) PT = 1; if (PT > 64) PT = 64;
+  int NIC = 1;
+  if (PT * L.O < 256) {
+    NIC = pow2_floor(256 / (PT * L.O));
+    const int cap = pow2_floor(L.I);
+    if (NIC > cap) NIC = cap;
+    if (NIC > 64) NIC = 64;
+  }
+  const size_t lds = (size_t)PT * L.I * (sizeof(EdgeRec) + J * 4) + (size_t)L.I * L.nk() * 4;
+  const int64_t blocks = (N + PT - 1) / PT;
+  fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, wt, y, N, L.I, L.O, L.G, L.act, PT, NIC);
+}
+
+template <int D, int D2>
+static void bwd_input_t(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
+                        int64_t N, hipStream_t st) {
+  const int64_t total = N * L.I;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  const size_t lds = (size_t)L.I * L.nk() * 4;
+  bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, wp, ga, N, L.I, L.O, L.G, L.act);
+}
+
+int generic_weight_chunks(int64_t N, int I, int O) {
+  // enough blocks to fill the chip, few enough that the partials stay small
+  const int tiles = ((I + kBwTI - 1) / kBwTI) * ((O + kBwTO - 1) / kBwTO);
+  int64_t want = (2048 + tiles - 1) / tiles;
+  const int64_t max_by_pts = (N + 255) / 256;
+  if (want > max_by_pts) want = max_by_pts;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+template <int D, int D2>
+static void bwd_weight_t(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                         int64_t N, hipStream_t st) {
+  constexpr int J = 1 + D + D2;
+  int64_t chunk = (N + nchunks - 1) / nchunks;
+  chunk = (chunk + kBwPT - 1) / kBwPT * kBwPT;
+  dim3 g((L.I + kBwTI - 1) / kBwTI, (L.O + kBwTO - 1) / kBwTO, nchunks);
+  const size_t lds = sizeof(EdgeRec) * kBwPT * kBwTI + (size_t)kBwPT * kBwTI * J * 4 +
+                     (size_t)kBwPT * kBwTO * J * 4 + (size_t)kBwTI * L.nk() * 4 + (size_t)L.C() * 256 * 4;
+  bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, part, N, L.I, L.O, L.G, L.act, chunk);
+}
+
+template <int D, int D2>
+static void residual_t(const float* x, int64_t sn, int64_t sd, const float* vjet, const float* target,
+                       float sigma, float rate, float inv_n, float* res, float* gy, float* loss_part,
+                       int nblocks, int64_t N, hipStream_t st) {
+  bs_residual_kernel<D, D2><<<nblocks, 256, 0, st>>>(x, sn, sd, vjet, target, sigma, rate, inv_n, res, gy,
+                                                     loss_part, N);
+}
+
+#define PDEKAN_DISPATCH_JET(D_, D2_, CALL)                       \
+  if ((D_) == 0 && (D2_) == 0) { CALL(0, 0); }                   \
+  else if ((D_) == 2 && (D2_) == 1) { CALL(2, 1); }              \
+  else if ((D_) == 6 && (D2_) == 5) { CALL(6, 5); }              \
+  else return false;
+
+bool launch_seed_jets(int D, int D2, const float* x, int64_t sn, int64_t sd, float* a, int64_t N, int I,
+                      hipStream_t st) {
+#define CALL(A, B) seed_t<A, B>(x, sn, sd, a, N, I, st)
+  PDEKAN_DISPATCH_JET(D, D2, CALL)
+#undef CALL
+  return true;
+}
+
+bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
+                        hipStream_t st) {
+#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st)
+  PDEKAN_DISPATCH_JET(D, D2, CALL)
+#undef CALL
+  return true;
+}
+
+bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, const float* wp,
+                              float* ga, int64_t N, hipStream_t st) {
+#define CALL(A, B) bwd_input_t<A, B>(L, a, gy, wp, ga, N, st)
+  PDEKAN_DISPATCH_JET(D, D2, CALL)
+#undef CALL
+  return true;
+}
+
+bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
+                               int nchunks, int64_t N, hipStream_t st) {
+#define CALL(A, B) bwd_weight_t<A, B>(L, a, gy, part, nchunks, N, st)
+  PDEKAN_DISPATCH_JET(D, D2, CALL)
+#undef CALL
+  return true;
+}
+
+void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* g_base, float* g_spline,
+                          float* g_scaler, int accumulate, hipStream_t st) {
+  const int edges = L.O * L.I;
+  const int blocks = (edges + 127) / 128;
+  reduce_unpack_kernel<<<blocks, 128, 0, st>>>(part, nchunks, L.spline_w, L.scaler, g_base, g_spline, g_scaler,
+                                               L.I, L.O, L.C(), accumulate);
+}
+
+bool launch_bs_residual(int D, const float* x, int64_t sn, int64_t sd, const float* vjet, const float* target,
+                        float sigma, float rate, float inv_n, float* res, float* gy, float* loss_part,
+                        int nblocks, int64_t N, hipStream_t st) {
+  if (D == 2) residual_t<2, 1>(x, sn, sd, vjet, target, sigma, rate, inv_n, res, gy, loss_part, nblocks, N, st);
+  else if (D == 6) residual_t<6, 5>(x, sn, sd, vjet, target, sigma, rate, inv_n, res, gy, loss_part, nblocks, N, st);
+  else return false;
+  return true;
+}
+
+void launch_loss_finish(const float* loss_part, int nparts, float inv_n, float* loss_out, int accumulate,
+                        hipStream_t st) {
+  loss_finish_kernel<<<1, 256, 0, st>>>(loss_part, nparts, inv_n, loss_out, accumulate);
+}
+
+}  // namespace pdekan

@@ -1,0 +1,50 @@
+// Internal launch interface shared by the kernel translation units and the
+// C-ABI layer.  Not installed; the public interface is include/pdekan.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace pdekan {
+
+// One KANLinear layer as the kernels see it (device pointers, caller-owned).
+struct LayerView {
+  int I, O, G, act;
+  const float* grid;       // [I][G+7]
+  const float* base_w;     // [O][I]
+  const float* spline_w;   // [O][I][G+3]
+  const float* scaler;     // [O][I] or nullptr
+  int C() const { return G + 3; }
+  int C1() const { return G + 4; }
+  int nk() const { return G + 7; }
+  size_t packed_floats() const { return (size_t)O * I * C1(); }
+};
+
+// kan_kernels.hip
+void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st);
+bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
+                      int I, hipStream_t st);
+bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
+                        hipStream_t st);
+bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
+                              const float* wp, float* ga, int64_t N, hipStream_t st);
+int generic_weight_chunks(int64_t N, int I, int O);
+bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
+                               int nchunks, int64_t N, hipStream_t st);
+void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* g_base, float* g_spline,
+                          float* g_scaler, int accumulate, hipStream_t st);
+bool launch_bs_residual(int D, const float* x, int64_t stride_n, int64_t stride_d, const float* vjet,
+                        const float* target, float sigma, float rate, float inv_n, float* res, float* gy,
+                        float* loss_part, int nblocks, int64_t N, hipStream_t st);
+void launch_loss_finish(const float* loss_part, int nparts, float inv_n, float* loss_out, int accumulate,
+                        hipStream_t st);
+
+// kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
+bool mfma_eligible(int D, int D2, const LayerView& L);
+int mfma_weight_chunks(int64_t N, const LayerView& L);
+void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st);
+void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
+                           int64_t N, hipStream_t st);
+void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                            int64_t N, hipStream_t st);
+
+}  // namespace pdekan

@@ -1,0 +1,185 @@
+// Per-feature math of the KAN layer: local cubic B-spline evaluation with
+// derivatives, base-activation derivatives, and the jet algebra that carries
+// (value, first derivatives, diagonal second derivatives) through a layer.
+//
+// The reference evaluates all G+k bases of a feature densely by Cox-de Boor
+// (efficient_kan/kan.py:78-111) and gets derivatives from autograd.  Only the
+// k+1 = 4 bases whose support contains x are non-zero, so here one interval
+// search is followed by the local de Boor triangle on the 6 knots around x and
+// by the closed-form derivative recurrences
+//     B'_{j,p} = p * ( B_{j,p-1}/(g_{j+p}-g_j) - B_{j+1,p-1}/(g_{j+p+1}-g_{j+1}) ).
+// Interval convention is the reference's: half-open [g_s, g_{s+1}); a point
+// outside [g_0, g_last) has every basis (and derivative) equal to zero.
+//
+// Everything is __host__ __device__ so the same code is unit-tested on the CPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define KAN_HD __host__ __device__ __forceinline__
+#else
+#define KAN_HD inline
+#endif
+
+namespace pdekan {
+
+constexpr int kOrder = 3;            // cubic splines only (every reference caller uses spline_order=3)
+constexpr int kActIdentity = 0;
+constexpr int kActSiLU = 1;
+
+KAN_HD float kan_rcp(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(v);
+#else
+  return 1.0f / v;
+#endif
+}
+
+KAN_HD float kan_exp(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __expf(v);
+#else
+  return expf(v);
+#endif
+}
+
+// Values and derivatives of the 4 non-zero cubic bases at x.
+//   c0 : index of the first of them (may be negative or run past C-1 near the
+//        ends of the extended grid; callers mask c0+m to [0, C-1]).
+//   inside = 0 : x lies outside the grid (or is NaN); all arrays are zero.
+struct Basis {
+  float b[4];    // B_{c0+m,3}(x)
+  float d1[4];   // first derivative
+  float d2[4];   // second derivative
+  float d3[4];   // third derivative (piecewise constant)
+  int c0;
+  int inside;
+};
+
+// Find s with g[s] <= x < g[s+1].  nk = number of knots.  A uniform guess is
+// corrected by walking, so non-uniform knots (after update_grid) are handled.
+template <typename KnotPtr>
+KAN_HD int find_interval(const KnotPtr g, int nk, float x) {
+  const float g0 = g[0], g1 = g[nk - 1];
+  float u = (x - g0) * kan_rcp(g1 - g0) * (float)(nk - 1);
+  int s = (u > 0.0f) ? (int)u : 0;          // NaN -> 0
+  if (s > nk - 2) s = nk - 2;
+  while (s > 0 && x < g[s]) --s;
+  while (s < nk - 2 && x >= g[s + 1]) ++s;
+  return s;
+}
+
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis(const KnotPtr g, int nk, float x, Basis& out) {
+  const int s = find_interval(g, nk, x);
+  out.c0 = s - kOrder;
+  out.inside = (x >= g[0]) && (x < g[nk - 1]);
+  // knots g[s-2] .. g[s+3], indices clamped: a clamped knot only ever feeds a
+  // basis whose index is outside [0, C-1], which callers drop.
+  const int last = nk - 1;
+  const float km2 = g[s - 2 < 0 ? 0 : s - 2];
+  const float km1 = g[s - 1 < 0 ? 0 : s - 1];
+  const float k0 = g[s];
+  const float k1 = g[s + 1];
+  const float k2 = g[s + 2 > last ? last : s + 2];
+  const float k3 = g[s + 3 > last ? last : s + 3];
+
+  const float r1 = kan_rcp(k1 - k0);
+  const float r2a = kan_rcp(k1 - km1), r2b = kan_rcp(k2 - k0);
+  const float r3a = kan_rcp(k1 - km2), r3b = kan_rcp(k2 - km1), r3c = kan_rcp(k3 - k0);
+
+  // order 1 (two non-zero): indices s-1, s
+  const float b1a = (k1 - x) * r1;
+  const float b1b = (x - k0) * r1;
+  // order 2 (three non-zero): indices s-2, s-1, s
+  const float u_a = b1a * r2a, u_b = b1b * r2b;
+  const float b2a = (k1 - x) * u_a;
+  const float b2b = (x - km1) * u_a + (k2 - x) * u_b;
+  const float b2c = (x - k0) * u_b;
+  // order 3 (four non-zero): indices s-3 .. s
+  const float q_a = b2a * r3a, q_b = b2b * r3b, q_c = b2c * r3c;
+  float b0 = (k1 - x) * q_a;
+  float b1 = (x - km2) * q_a + (k2 - x) * q_b;
+  float b2 = (x - km1) * q_b + (k3 - x) * q_c;
+  float b3 = (x - k0) * q_c;
+  // first derivative: 3 * (q[j] - q[j+1])
+  float e0 = -3.0f * q_a, e1 = 3.0f * (q_a - q_b), e2 = 3.0f * (q_b - q_c), e3 = 3.0f * q_c;
+  // second derivative: order-2 first derivatives are 2*(u[j]-u[j+1])
+  const float w_a = -2.0f * u_a * r3a, w_b = 2.0f * (u_a - u_b) * r3b, w_c = 2.0f * u_b * r3c;
+  float f0 = -3.0f * w_a, f1 = 3.0f * (w_a - w_b), f2 = 3.0f * (w_b - w_c), f3 = 3.0f * w_c;
+  const float m = out.inside ? 1.0f : 0.0f;   // outside the grid everything is zero
+  out.b[0] = b0 * m; out.b[1] = b1 * m; out.b[2] = b2 * m; out.b[3] = b3 * m;
+  out.d1[0] = e0 * m; out.d1[1] = e1 * m; out.d1[2] = e2 * m; out.d1[3] = e3 * m;
+  out.d2[0] = f0 * m; out.d2[1] = f1 * m; out.d2[2] = f2 * m; out.d2[3] = f3 * m;
+  if (kNeedD3) {
+    const float z_a = 2.0f * r1 * r2a * r3a, z_b = -2.0f * r1 * (r2a + r2b) * r3b,
+                z_c = 2.0f * r1 * r2b * r3c;
+    out.d3[0] = -3.0f * z_a * m; out.d3[1] = 3.0f * (z_a - z_b) * m;
+    out.d3[2] = 3.0f * (z_b - z_c) * m; out.d3[3] = 3.0f * z_c * m;
+  } else {
+    out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
+  }
+  if (!out.inside) {   // NaN/inf products above must not leak
+    for (int i = 0; i < 4; ++i) { out.b[i] = out.d1[i] = out.d2[i] = out.d3[i] = 0.0f; }
+  }
+}
+
+// Base activation and its first three derivatives (kan.py:158; the scripts
+// pass nn.Identity, the module default is SiLU).
+struct Act { float f0, f1, f2, f3; };
+
+KAN_HD Act eval_act(int kind, float x) {
+  Act a;
+  if (kind == kActSiLU) {
+    const float s = kan_rcp(1.0f + kan_exp(-x));
+    const float sp = s * (1.0f - s);        // sigmoid'
+    const float t = 1.0f - 2.0f * s;
+    a.f0 = x * s;
+    a.f1 = s * (1.0f + x * (1.0f - s));
+    a.f2 = sp * (2.0f + x * t);
+    a.f3 = sp * (t * (3.0f + x * t) - 2.0f * x * sp);
+  } else {
+    a.f0 = x; a.f1 = 1.0f; a.f2 = 0.0f; a.f3 = 0.0f;
+  }
+  return a;
+}
+
+// Jet layout of one scalar quantity carried through the network, J = 1+D+D2
+// floats:  [0] value, [1..D] d/dx_d, [1+D..D+D2] d2/dx_d^2 for d < D2.
+template <int D, int D2>
+struct JetShape {
+  static constexpr int kD = D, kD2 = D2, kJ = 1 + D + D2;
+};
+
+// Coefficients that turn (phi, phi', phi'') of one edge function into the
+// output-jet contribution of that edge, given the input jet a[]:
+//   y[0]      += phi
+//   y[1+d]    += phi'  * a[1+d]
+//   y[1+D+d]  += phi'' * a[1+d]^2 + phi' * a[1+D+d]
+template <int D, int D2>
+KAN_HD void jet_accumulate(float* y, const float* a, float p0, float p1, float p2) {
+  y[0] += p0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) y[1 + d] += p1 * a[1 + d];
+#pragma unroll
+  for (int d = 0; d < D2; ++d) y[1 + D + d] += p2 * a[1 + d] * a[1 + d] + p1 * a[1 + D + d];
+}
+
+// The three scalars that pair with (phi, phi', phi'') when a cotangent gy[] of
+// the output jet is pulled back onto one edge:  <gy, dy> = A0*phi + A1*phi' + A2*phi''.
+template <int D, int D2>
+KAN_HD void jet_pullback_coeffs(const float* gy, const float* a, float& A0, float& A1, float& A2) {
+  A0 = gy[0];
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) s1 += gy[1 + d] * a[1 + d];
+#pragma unroll
+  for (int d = 0; d < D2; ++d) {
+    s1 += gy[1 + D + d] * a[1 + D + d];
+    s2 += gy[1 + D + d] * a[1 + d] * a[1 + d];
+  }
+  A1 = s1; A2 = s2;
+}
+
+}  // namespace pdekan

@@ -1,0 +1,306 @@
+// C ABI of libpdekan (see include/pdekan.h): argument checks, workspace
+// carving and the sequence of kernel launches of a layer / model / train step.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pdekan.h"
+#include "kan_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return PDEKAN_OK;
+}
+
+bool jet_supported(int d, int d2) { return (d == 0 && d2 == 0) || (d == 2 && d2 == 1) || (d == 6 && d2 == 5); }
+
+int to_view(const PdekanLayer* l, pdekan::LayerView& v) {
+  if (!l) return fail(PDEKAN_ERR_ARG, "layer is NULL");
+  if (l->spline_order != 3) return fail(PDEKAN_ERR_ARG, "spline_order %d unsupported (cubic only)", l->spline_order);
+  if (l->in_features < 1 || l->out_features < 1 || l->grid_size < 1 || l->grid_size > 64)
+    return fail(PDEKAN_ERR_ARG, "bad layer shape in=%d out=%d grid=%d", l->in_features, l->out_features, l->grid_size);
+  if (l->act_kind != PDEKAN_ACT_IDENTITY && l->act_kind != PDEKAN_ACT_SILU)
+    return fail(PDEKAN_ERR_ARG, "act_kind %d unsupported", l->act_kind);
+  if (!l->grid || !l->base_weight || !l->spline_weight) return fail(PDEKAN_ERR_ARG, "layer has NULL parameter pointers");
+  v.I = l->in_features; v.O = l->out_features; v.G = l->grid_size; v.act = l->act_kind;
+  v.grid = l->grid; v.base_w = l->base_weight; v.spline_w = l->spline_weight; v.scaler = l->spline_scaler;
+  return PDEKAN_OK;
+}
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Carver {
+  char* base; size_t size, used = 0; bool ok = true;
+  Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n) {}
+  float* take(size_t floats) {
+    const size_t bytes = align_up(floats * sizeof(float));
+    if (used + bytes > size) { ok = false; return nullptr; }
+    float* r = reinterpret_cast<float*>(base + used);
+    used += bytes;
+    return r;
+  }
+};
+
+int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  if (pdekan::mfma_eligible(D, D2, L)) return pdekan::mfma_weight_chunks(n, L);
+  return pdekan::generic_weight_chunks(n, L.I, L.O);
+}
+
+size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  const size_t packed = align_up(L.packed_floats() * 4) / 4;
+  return 2 * packed + align_up((size_t)weight_chunks(D, D2, L, n) * L.packed_floats() * 4) / 4;
+}
+
+int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, float* y, int64_t n,
+                hipStream_t st) {
+  if (pdekan::mfma_eligible(D, D2, L)) {
+    pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
+  } else if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st)) {
+    return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+  }
+  return check_launch("layer forward");
+}
+
+int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* gy, const float* wp,
+                 float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st) {
+  const bool mf = pdekan::mfma_eligible(D, D2, L);
+  if (g) {
+    if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
+      return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
+    const int nch = weight_chunks(D, D2, L, n);
+    if (mf) pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st);
+    else if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st))
+      return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+    pdekan::launch_reduce_unpack(L, part, nch, g->base_weight, g->spline_weight,
+                                 L.scaler ? g->spline_scaler : nullptr, accumulate, st);
+  }
+  if (ga) {
+    if (mf) pdekan::launch_bwd_input_mfma(L, a, gy, wp, ga, n, st);
+    else if (!pdekan::launch_bwd_input_generic(D, D2, L, a, gy, wp, ga, n, st))
+      return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+  }
+  return check_launch("layer backward");
+}
+
+struct ModelPlan {
+  std::vector<pdekan::LayerView> L;
+  int D, D2, J;
+  int64_t mb;           // points per micro-batch
+  int maxw;             // widest activation
+  size_t part_floats;   // largest partial buffer
+};
+
+int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2, int64_t micro_batch, ModelPlan& P) {
+  if (!layers || n_layers < 1) return fail(PDEKAN_ERR_ARG, "no layers");
+  if (n < 1) return fail(PDEKAN_ERR_ARG, "n must be positive");
+  if (!jet_supported(D, D2)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+  P.L.resize(n_layers);
+  P.D = D; P.D2 = D2; P.J = 1 + D + D2;
+  P.mb = (micro_batch <= 0 || micro_batch > n) ? n : micro_batch;
+  P.maxw = 0; P.part_floats = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    int rc = to_view(&layers[l], P.L[l]);
+    if (rc) return rc;
+    if (l > 0 && P.L[l].I != P.L[l - 1].O) return fail(PDEKAN_ERR_ARG, "layer %d input width mismatch", l);
+    if (P.L[l].I > P.maxw) P.maxw = P.L[l].I;
+    if (P.L[l].O > P.maxw) P.maxw = P.L[l].O;
+    const size_t pf = (size_t)weight_chunks(D, D2, P.L[l], P.mb) * P.L[l].packed_floats();
+    if (pf > P.part_floats) P.part_floats = pf;
+  }
+  return PDEKAN_OK;
+}
+
+struct ModelWs {
+  std::vector<float*> wp, wt, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
+  float* g[2];
+  float* part;
+  float* loss_part;
+};
+
+constexpr int kLossBlocks = 1024;
+
+bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* need) {
+  Carver c(ws, ws ? ws_bytes : 0);
+  const size_t nl = P.L.size();
+  size_t total = 0;
+  auto take = [&](size_t floats) -> float* {
+    total += align_up(floats * 4);
+    return ws ? c.take(floats) : nullptr;
+  };
+  W.wp.resize(nl); W.wt.resize(nl); W.act.resize(nl + 1);
+  for (size_t l = 0; l < nl; ++l) { W.wp[l] = take(P.L[l].packed_floats()); W.wt[l] = take(P.L[l].packed_floats()); }
+  for (size_t l = 0; l <= nl; ++l) {
+    const int w = (l < nl) ? P.L[l].I : P.L[nl - 1].O;
+    W.act[l] = take((size_t)P.mb * w * P.J);
+  }
+  W.g[0] = take((size_t)P.mb * P.maxw * P.J);
+  W.g[1] = take((size_t)P.mb * P.maxw * P.J);
+  W.part = take(P.part_floats);
+  W.loss_part = take(kLossBlocks);
+  if (need) *need = total;
+  return ws ? c.ok : true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdekan_version(void) { return 100; }
+
+const char* pdekan_last_error(void) { return g_err; }
+
+int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t n, int32_t d, int32_t n_dir,
+                     int32_t n_second, float* jet, void* stream) {
+  if (!x || !jet || n < 1 || d < 1) return fail(PDEKAN_ERR_ARG, "seed_jets: bad arguments");
+  if (n_dir != 0 && n_dir != d) return fail(PDEKAN_ERR_ARG, "seed_jets: n_dir must be 0 or d");
+  if (!pdekan::launch_seed_jets(n_dir, n_second, x, stride_n, stride_d, jet, n, d, (hipStream_t)stream))
+    return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
+  return check_launch("seed_jets");
+}
+
+size_t pdekan_layer_workspace_bytes(const PdekanLayer* layer, int64_t n, int32_t n_dir, int32_t n_second) {
+  pdekan::LayerView L;
+  if (to_view(layer, L) || n < 1) return 0;
+  return layer_ws_floats(n_dir, n_second, L, n) * sizeof(float) + 256;
+}
+
+int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
+                         int32_t n_second, void* ws, size_t ws_bytes, void* stream) {
+  pdekan::LayerView L;
+  int rc = to_view(layer, L);
+  if (rc) return rc;
+  if (!x_jet || !y_jet || n < 1) return fail(PDEKAN_ERR_ARG, "layer_forward: bad arguments");
+  if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  Carver c(ws, ws_bytes);
+  float* wp = c.take(L.packed_floats());
+  float* wt = c.take(L.packed_floats());
+  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  pdekan::launch_pack_weights(L, wp, wt, st);
+  return run_forward(n_dir, n_second, L, x_jet, wt, y_jet, n, st);
+}
+
+int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const float* gy_jet, int64_t n,
+                          int32_t n_dir, int32_t n_second, float* gx_jet, const PdekanLayerGrad* grads,
+                          int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+  pdekan::LayerView L;
+  int rc = to_view(layer, L);
+  if (rc) return rc;
+  if (!x_jet || !gy_jet || n < 1) return fail(PDEKAN_ERR_ARG, "layer_backward: bad arguments");
+  if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  Carver c(ws, ws_bytes);
+  float* wp = c.take(L.packed_floats());
+  float* wt = c.take(L.packed_floats());
+  float* part = c.take((size_t)weight_chunks(n_dir, n_second, L, n) * L.packed_floats());
+  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  pdekan::launch_pack_weights(L, wp, wt, st);
+  return run_backward(n_dir, n_second, L, x_jet, gy_jet, wp, gx_jet, part, grads, accumulate, n, st);
+}
+
+size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers, int64_t n, int32_t n_dir,
+                                    int32_t n_second, int64_t micro_batch) {
+  ModelPlan P;
+  if (make_plan(layers, n_layers, n, n_dir, n_second, micro_batch, P)) return 0;
+  ModelWs W;
+  size_t need = 0;
+  carve(P, nullptr, 0, W, &need);
+  return need + 256;
+}
+
+int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const float* x, int64_t stride_n,
+                             int64_t stride_d, int64_t n, int32_t n_dir, int32_t n_second, float* out_jet,
+                             int64_t micro_batch, void* ws, size_t ws_bytes, void* stream) {
+  ModelPlan P;
+  int rc = make_plan(layers, n_layers, n, n_dir, n_second, micro_batch, P);
+  if (rc) return rc;
+  if (!x || !out_jet) return fail(PDEKAN_ERR_ARG, "model_forward_jet: NULL buffers");
+  if (n_dir != 0 && n_dir != P.L[0].I) return fail(PDEKAN_ERR_ARG, "n_dir must be 0 or the input width");
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  ModelWs W;
+  if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int nl = (int)P.L.size();
+  for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+  const int out_w = P.L[nl - 1].O;
+  for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
+    const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
+    pdekan::launch_seed_jets(P.D, P.D2, x + p0 * stride_n, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    for (int l = 0; l < nl; ++l) {
+      float* dst = (l == nl - 1) ? out_jet + p0 * out_w * P.J : W.act[l + 1];
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], dst, m, st);
+      if (rc) return rc;
+    }
+  }
+  return check_launch("model_forward_jet");
+}
+
+int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, int64_t stride_n,
+                   int64_t stride_d, const float* target, int64_t n, int64_t n_global, float sigma, float rate,
+                   float* loss_out, float* res_out, const PdekanLayerGrad* grads, int32_t accumulate,
+                   int64_t micro_batch, void* ws, size_t ws_bytes, void* stream) {
+  if (!layers || n_layers < 1) return fail(PDEKAN_ERR_ARG, "no layers");
+  const int d = layers[0].in_features;
+  ModelPlan P;
+  int rc = make_plan(layers, n_layers, n, d, d - 1, micro_batch, P);
+  if (rc) return rc;
+  if (!x) return fail(PDEKAN_ERR_ARG, "bs_step: x is NULL");
+  if (P.L.back().O != 1) return fail(PDEKAN_ERR_ARG, "bs_step: the last layer must have one output");
+  if (n_global < n) return fail(PDEKAN_ERR_ARG, "bs_step: n_global < n");
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  ModelWs W;
+  if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int nl = (int)P.L.size();
+  const float inv_n = 1.0f / (float)n_global;
+  for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+  bool first = true;
+  for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
+    const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
+    const float* xs = x + p0 * stride_n;
+    pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    for (int l = 0; l < nl; ++l) {
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.act[l + 1], m, st);
+      if (rc) return rc;
+    }
+    int nblocks = (int)((m + 255) / 256);
+    if (nblocks > kLossBlocks) nblocks = kLossBlocks;
+    float* gcur = grads ? W.g[0] : nullptr;
+    if (!pdekan::launch_bs_residual(P.D, xs, stride_n, stride_d, W.act[nl], target ? target + p0 : nullptr, sigma,
+                                    rate, inv_n, res_out ? res_out + p0 : nullptr, gcur, W.loss_part, nblocks, m, st))
+      return fail(PDEKAN_ERR_ARG, "bs_step: %d input columns unsupported (2 or 6)", d);
+    if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
+    if (grads) {
+      int cur = 0;
+      for (int l = nl - 1; l >= 0; --l) {
+        float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
+        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], gnext, W.part, &grads[l],
+                          (accumulate || !first) ? 1 : 0, m, st);
+        if (rc) return rc;
+        cur ^= 1;
+      }
+    }
+    first = false;
+  }
+  return check_launch("bs_step");
+}
+
+}  // extern "C"

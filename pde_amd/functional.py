@@ -1,0 +1,132 @@
+"""``torch.autograd.Function`` wrappers around the C ABI of libpdekan.so.
+
+PyTorch is used here for device memory, streams and the autograd tape only;
+every number comes out of the HIP kernels.  Tensors handed to the library must
+live on a ROCm device - a CPU tensor raises instead of taking another path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import PdekanLayer, PdekanLayerGrad
+
+ACT_IDENTITY = 0
+ACT_SILU = 1
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"pde_amd: {what} is on {t.device}; the KAN hot path runs only on a ROCm GPU "
+            "(there is no CPU implementation in this package)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"pde_amd: {what} must be float32, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def layer_struct(grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size, spline_order) -> PdekanLayer:
+    out_f, in_f = base_weight.shape
+    return PdekanLayer(in_f, out_f, grid_size, spline_order, act_kind, 0,
+                       grid.data_ptr(), base_weight.data_ptr(), spline_weight.data_ptr(),
+                       0 if spline_scaler is None else spline_scaler.data_ptr())
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    # torch's caching allocator returns 512-byte aligned blocks
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _prep(t: Optional[torch.Tensor], what: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = t.detach()
+    _require_gpu(t, what)
+    return t.contiguous()
+
+
+def seed_jets(x: torch.Tensor, n_dir: int, n_second: int) -> torch.Tensor:
+    """Input jets ``[N, d, J]`` of points ``x [N, d]`` (strided views welcome)."""
+    _require_gpu(x, "x")
+    assert x.dim() == 2
+    lib = _lib.load()
+    n, d = x.shape
+    jet = torch.empty(n, d, 1 + n_dir + n_second, dtype=torch.float32, device=x.device)
+    xd = x.detach()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pdekan_seed_jets(_ptr(xd), xd.stride(0), xd.stride(1), n, d, n_dir, n_second,
+                                        _ptr(jet), _stream(x.device)))
+    return jet
+
+
+class _KanLayerJet(torch.autograd.Function):
+    """y_jet = layer(x_jet); backward gives gx_jet and the parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x_jet, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size,
+                spline_order, n_dir, n_second):
+        lib = _lib.load()
+        xj = _prep(x_jet, "input")
+        g, bw, sw = _prep(grid, "grid"), _prep(base_weight, "base_weight"), _prep(spline_weight, "spline_weight")
+        sc = _prep(spline_scaler, "spline_scaler")
+        n, in_f, j = xj.shape
+        assert j == 1 + n_dir + n_second and in_f == bw.shape[1]
+        layer = layer_struct(g, bw, sw, sc, act_kind, grid_size, spline_order)
+        y = torch.empty(n, bw.shape[0], j, dtype=torch.float32, device=xj.device)
+        with torch.cuda.device(xj.device):
+            ws = _workspace(lib.pdekan_layer_workspace_bytes(ctypes.byref(layer), n, n_dir, n_second), xj.device)
+            _lib.check(lib.pdekan_layer_forward(ctypes.byref(layer), _ptr(xj), _ptr(y), n, n_dir, n_second,
+                                                _ptr(ws), ws.numel(), _stream(xj.device)))
+        ctx.save_for_backward(xj, g, bw, sw, sc if sc is not None else torch.empty(0))
+        ctx.meta = (act_kind, grid_size, spline_order, n_dir, n_second, sc is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xj, g, bw, sw, sc = ctx.saved_tensors
+        act_kind, grid_size, spline_order, n_dir, n_second, has_sc = ctx.meta
+        sc = sc if has_sc else None
+        gy = _prep(gy, "grad_output")
+        n = xj.shape[0]
+        layer = layer_struct(g, bw, sw, sc, act_kind, grid_size, spline_order)
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[2:5])
+        gx = torch.empty_like(xj) if need_x else None
+        gbw = torch.empty_like(bw) if need_w else None
+        gsw = torch.empty_like(sw) if need_w else None
+        gsc = torch.empty_like(sc) if (need_w and has_sc) else None
+        grads = PdekanLayerGrad(0 if gbw is None else gbw.data_ptr(), 0 if gsw is None else gsw.data_ptr(),
+                                0 if gsc is None else gsc.data_ptr())
+        with torch.cuda.device(xj.device):
+            ws = _workspace(lib.pdekan_layer_workspace_bytes(ctypes.byref(layer), n, n_dir, n_second), xj.device)
+            _lib.check(lib.pdekan_layer_backward(ctypes.byref(layer), _ptr(xj), _ptr(gy), n, n_dir, n_second,
+                                                 _ptr(gx), ctypes.byref(grads) if need_w else None, 0,
+                                                 _ptr(ws), ws.numel(), _stream(xj.device)))
+        return gx, None, gbw, gsw, gsc, None, None, None, None, None
+
+
+def kan_layer_jet(x_jet, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size, spline_order,
+                  n_dir, n_second):
+    return _KanLayerJet.apply(x_jet, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size,
+                              spline_order, n_dir, n_second)
+
+
+def kan_layer(x, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size, spline_order):
+    """``KANLinear.forward`` on a 2-D batch ``[N, in] -> [N, out]`` with
+    first-order autograd (values are jets with J = 1)."""
+    _require_gpu(x, "x")
+    y = _KanLayerJet.apply(x.contiguous().unsqueeze(-1), grid, base_weight, spline_weight, spline_scaler,
+                           act_kind, grid_size, spline_order, 0, 0)
+    return y.squeeze(-1)

@@ -1,0 +1,154 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/pdekan.h
+declares; the module mirrors the reference's interface and seeded init."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_state_dict
+
+
+def test_library_exports_every_declared_symbol():
+    from pde_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "pdekan.h")).read()
+    declared = set(re.findall(r"\b(pdekan_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.pdekan_version() >= 100
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    from pde_amd import _lib
+    lib = _lib.load()
+    assert lib.pdekan_layer_workspace_bytes(None, 16, 0, 0) == 0
+    layer = _lib.PdekanLayer(2, 5, 5, 2, 1, 0, 1, 1, 1, 1)      # spline_order 2: unsupported
+    assert lib.pdekan_layer_workspace_bytes(layer, 16, 0, 0) == 0
+    assert b"spline_order" in lib.pdekan_last_error()
+    rc = lib.pdekan_seed_jets(None, 2, 1, 16, 2, 2, 1, None, None)
+    assert rc == -1
+
+
+@pytest.mark.parametrize("case", ["cfg1_init", "cfg2_silu", "cfg4_narrow", "cfg5_narrow"])
+def test_seeded_init_matches_reference(golden, case):
+    """Same RNG consumption order as kan.py:56-76: base_weight, spline_scaler and
+    grid are bit-identical to the reference's seeded construction.
+
+    spline_weight is the solution of an lstsq through G+1 noise samples with
+    G+3 unknowns (kan.py:67-73, :131-133) - under-determined, and
+    torch.linalg.lstsq is not run-to-run reproducible on it even inside the
+    reference: two seeded constructions of the reference differ by 6e-3 in the
+    coefficients of about one input feature per layer (measured in the build
+    container), and for that feature even the fitted curve at the sample knots
+    moves.  So the fitted curve is compared per input feature (= per lstsq
+    batch item), and at most two features per layer may deviate - the
+    reference's own run-to-run spread."""
+    from pde_amd import KAN
+    from pde_amd.spline_host import dense_bsplines
+    rec = golden(case)
+    torch.manual_seed(int(rec["seed"]))
+    act = {"silu": torch.nn.SiLU, "identity": torch.nn.Identity}[str(rec["act"])]
+    m = KAN([int(w) for w in rec["widths"]], grid_size=int(rec["grid_size"]), base_activation=act)
+    sd = m.state_dict()
+    init = golden_state_dict(rec, "init.")
+    assert set(sd) == set(init)
+    for k in sd:
+        if k.endswith("spline_weight"):
+            grid = sd[k.replace("spline_weight", "grid")]
+            bases = dense_bsplines(grid.T[3:-3], grid, 3)                 # [G+1, in, coeff]
+            mine = torch.einsum("gic,oic->gio", bases, sd[k])
+            ref = torch.einsum("gic,oic->gio", bases, init[k])
+            per_feature = (mine - ref).abs().amax(dim=(0, 2))
+            assert int((per_feature > 2e-6).sum()) <= 2, (k, per_feature)
+            assert sd[k].abs().max().item() <= 4 * init[k].abs().max().item() + 1e-3
+        else:
+            assert torch.equal(sd[k], init[k]), k
+
+
+def test_module_surface():
+    from pde_amd import KAN, KANLinear
+    layer = KANLinear(3, 4)
+    assert (layer.in_features, layer.out_features, layer.grid_size, layer.spline_order) == (3, 4, 5, 3)
+    assert layer.grid.shape == (3, 12) and layer.spline_weight.shape == (4, 3, 8)
+    assert isinstance(layer.base_activation, torch.nn.SiLU)
+    assert [n for n, _ in layer.named_parameters()] == ["base_weight", "spline_weight", "spline_scaler"]
+    no_scale = KANLinear(3, 4, enable_standalone_scale_spline=False)
+    assert not hasattr(no_scale, "spline_scaler")
+    m = KAN([2, 5, 1])
+    assert list(m.state_dict()) == [f"layers.{l}.{k}" for l in range(2)
+                                    for k in ("base_weight", "spline_weight", "spline_scaler", "grid")]
+    for name in ("reset_parameters", "b_splines", "curve2coeff", "scaled_spline_weight", "forward", "update_grid",
+                 "regularization_loss"):
+        assert hasattr(layer, name)
+
+
+def test_non_hot_methods_match_reference(golden):
+    """update_grid / curve2coeff / regularization_loss are ordinary tensor code
+    and run on the CPU: the fixture taken after the reference's
+    ``model(x, update_grid=True)`` pins the grid they produce."""
+    from pde_amd import KANLinear
+    rec = golden("updated_grid")
+    sd = golden_state_dict(rec)
+    layer = KANLinear(2, 8)
+    layer.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith("layers.0.")})
+    x = torch.from_numpy(rec["x"])
+    b = layer.b_splines(x)
+    assert b.shape == (x.size(0), 2, 8)
+    inside = (x >= layer.grid[:, 0]) & (x < layer.grid[:, -1])
+    # inside the non-extended part of the grid the bases sum to one
+    core = (x >= layer.grid[:, 3]) & (x < layer.grid[:, -4])
+    assert torch.allclose(b.sum(-1)[core], torch.ones(int(core.sum())), atol=1e-5)
+    assert torch.all(b[~inside] == 0)
+    reg = layer.regularization_loss()
+    l1 = layer.spline_weight.abs().mean(-1)
+    p = l1 / l1.sum()
+    assert torch.allclose(reg, l1.sum() - (p * p.log()).sum())
+    # refit: coefficients reproduce the curve they were fitted to
+    lo, hi = layer.grid[:, 0], layer.grid[:, -1]
+    xs = lo + (hi - lo) * torch.rand(256, 2, generator=torch.Generator().manual_seed(3))   # full rank
+    with torch.no_grad():
+        y = torch.bmm(layer.b_splines(xs).permute(1, 0, 2), layer.scaled_spline_weight.permute(1, 2, 0)).permute(1, 0, 2)
+        coeff = layer.curve2coeff(xs, y)
+        y2 = torch.bmm(layer.b_splines(xs).permute(1, 0, 2), coeff.permute(1, 2, 0)).permute(1, 0, 2)
+    assert torch.allclose(y, y2, atol=1e-4)
+
+
+def test_update_grid_matches_reference_fixture(golden):
+    """Replay the reference's update_grid call of the fixture (same seed, same
+    samples) with this package's tensor code and compare grids and weights."""
+    from pde_amd import KAN
+    rec = golden("updated_grid")
+    seed = int(rec["seed"])
+    torch.manual_seed(seed)
+    m = KAN([2, 8, 1], grid_size=5)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    # make_golden.special_points consumes the generator before update_grid's samples
+    torch.rand(128, 2, generator=gen)
+    torch.rand(12 + 6, 2, generator=gen)
+    samples = torch.rand(256, 2, generator=gen) * 1.4 - 0.2
+    # layer 0 only: layer 1's update needs layer 0's forward, which is GPU-only
+    m.layers[0].update_grid(samples)
+    sd = golden_state_dict(rec)
+    assert torch.allclose(m.layers[0].grid, sd["layers.0.grid"], atol=1e-6)
+    assert torch.allclose(m.layers[0].spline_weight, sd["layers.0.spline_weight"], atol=2e-4)
+
+
+def test_install_as_efficient_kan():
+    import sys
+    import pde_amd
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.startswith("efficient_kan")}
+    try:
+        pde_amd.install_as_efficient_kan()
+        from efficient_kan import KAN, KANLinear
+        assert KAN is pde_amd.KAN and KANLinear is pde_amd.KANLinear
+    finally:
+        for k in [k for k in sys.modules if k.startswith("efficient_kan")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -1,0 +1,169 @@
+"""HIP path (through the C ABI) against the oracle and the golden fixtures.
+Runs on the GPU box only: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, golden_state_dict, max_rel
+from oracle import kan_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # max|a-b|/max|b| per tensor, fp32
+
+
+def build_model(rec, device="cuda"):
+    from pde_amd import KAN
+    act = {"silu": torch.nn.SiLU, "identity": torch.nn.Identity}[str(rec["act"])]
+    m = KAN([int(w) for w in rec["widths"]], grid_size=int(rec["grid_size"]), base_activation=act)
+    m.load_state_dict(golden_state_dict(rec))
+    return m.to(device)
+
+
+def check(val, rec, key, tol=TOL):
+    r32, r64 = rec[key], rec[key.replace(".", "64.", 1) if "." in key else key + "64"]
+    v = val.detach().cpu().numpy() if torch.is_tensor(val) else val
+    assert max_rel(v, r64) <= tol, (key, max_rel(v, r64))
+    # the fp32 reference carries its own rounding noise; allow it on top
+    assert max_rel(v, r32) <= tol + max_rel(r32, r64), (key, max_rel(v, r32))
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_fused_step_matches_reference(golden, case):
+    from pde_amd.pinn import BlackScholesStep
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    step = BlackScholesStep(m)
+    res = torch.empty(x.size(0), device="cuda")
+    loss = step(x, residual_out=res)
+    torch.cuda.synchronize()
+    check(res, rec, "res")
+    check(loss, rec, "loss")
+    for name, p in m.named_parameters():
+        check(p.grad, rec, f"grad.{name}")
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg2_silu", "cfg5_narrow", "updated_grid"])
+def test_fused_step_micro_batches_agree(golden, case):
+    from pde_amd.pinn import BlackScholesStep
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    full = BlackScholesStep(m)
+    l0 = full(x).item()
+    g0 = full.flat_grad.clone()
+    mb = BlackScholesStep(m, micro_batch=37)
+    l1 = mb(x).item()
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert max_rel(mb.flat_grad.cpu(), g0.cpu()) <= 2e-6
+    check(mb.flat_grad[: m.layers[0].base_weight.numel()].view_as(m.layers[0].base_weight), rec,
+          "grad.layers.0.base_weight")
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg1_identity", "cfg2_silu", "cfg5_narrow", "updated_grid"])
+def test_forward_jet_matches_reference(golden, case):
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    d = x.size(1)
+    jet = m.forward_jet(x)
+    assert jet.shape == (x.size(0), 1, 2 * d)
+    check(jet[:, 0, 0], rec, "v")
+    check(jet[:, 0, 1:1 + d], rec, "first")
+    check(jet[:, 0, 1 + d:], rec, "second")
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg2_identity", "cfg4_narrow", "deeponet_trunk"])
+def test_autograd_through_forward_jet(golden, case):
+    """Residual + loss in tensor ops on top of forward_jet, backward through the
+    jet kernels: must give the fused step's (= the reference's) gradients."""
+    from pde_amd.pinn import bs_residual_from_jet
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    res = bs_residual_from_jet(x, m.forward_jet(x))
+    loss = (res ** 2).mean()
+    loss.backward()
+    check(res, rec, "res")
+    check(loss, rec, "loss")
+    for name, p in m.named_parameters():
+        check(p.grad, rec, f"grad.{name}")
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg2_identity", "cfg5_narrow", "updated_grid"])
+def test_plain_forward_backward(golden, case):
+    """KAN.forward + loss.backward(): the data-fit use of the layer (run1.py:134-141)."""
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda().requires_grad_(True)
+    y = m(x)
+    gy = torch.linspace(-1.0, 1.0, y.numel(), device="cuda").view_as(y)
+    (y * gy).sum().backward()
+    check(y, rec, "y")
+    check(x.grad, rec, "gx")
+    for name, p in m.named_parameters():
+        check(p.grad, rec, f"vgrad.{name}")
+
+
+def test_noncontiguous_and_batched_inputs(golden):
+    """The scripts feed a permuted stack (strides (1, n), run1.py:101-106) and
+    KANLinear accepts any leading dims (kan.py:155-165)."""
+    rec = golden("deeponet_trunk")
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    y_ref = m(x)
+    xt = torch.stack([x[:, 0].clone(), x[:, 1].clone()]).permute(1, 0)
+    assert not xt.is_contiguous()
+    assert torch.equal(m(xt), y_ref)
+    assert torch.equal(m.forward_jet(xt), m.forward_jet(x))
+    n = (x.size(0) // 2) * 2
+    y3 = m(x[:n].view(2, n // 2, 2))
+    assert y3.shape == (2, n // 2, 1)
+    assert torch.equal(y3.view(n, 1), y_ref[:n])
+    with pytest.raises(AssertionError):
+        m(torch.zeros(4, 3, device="cuda"))
+
+
+def test_cpu_tensor_is_refused(golden):
+    rec = golden("cfg1_silu")
+    m = build_model(rec, device="cpu")
+    with pytest.raises(RuntimeError, match="ROCm GPU"):
+        m(torch.zeros(4, 2))
+
+
+def test_large_batch_properties():
+    """Full-size behaviour through size-independent properties: the fused step
+    on 2^18 points equals the sum of its two halves (additivity of the loss and
+    of the gradients), and a permutation of the points changes nothing beyond
+    fp32 reassociation."""
+    from pde_amd import KAN
+    from pde_amd.pinn import BlackScholesStep
+    torch.manual_seed(0)
+    m = KAN([2, 64, 64, 1], grid_size=10).cuda()
+    g = torch.Generator().manual_seed(0)
+    n = 1 << 18
+    x = torch.rand(n, 2, generator=g).cuda()
+    step = BlackScholesStep(m)
+    l_all = step(x).item()
+    g_all = step.flat_grad.clone()
+    la = step(x[: n // 2], n_global=n).item()
+    ga = step.flat_grad.clone()
+    lb = step(x[n // 2:], n_global=n).item()
+    gb = step.flat_grad.clone()
+    assert abs(l_all - (la + lb)) <= 1e-5 * abs(l_all)
+    assert max_rel((ga + gb).cpu(), g_all.cpu()) <= 1e-5
+    perm = torch.randperm(n, generator=g).cuda()
+    lp = step(x[perm]).item()
+    assert abs(lp - l_all) <= 1e-5 * abs(l_all)
+    assert max_rel(step.flat_grad.cpu(), g_all.cpu()) <= 1e-5
+    # against the oracle on a slice the CPU finishes in seconds
+    sub = x[:2048].cpu()
+    layers = O.layers_from_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    ref = O.pinn_step(sub, layers, "silu")
+    res = torch.empty(2048, device="cuda")
+    l_sub = step(x[:2048], residual_out=res).item()
+    assert max_rel(res.cpu(), ref["res"]) <= 1e-5
+    assert abs(l_sub - ref["loss"].item()) <= 1e-5 * abs(ref["loss"].item())
+    flat_ref = torch.cat([ref["grads"][l][k].flatten() for l in range(3)
+                          for k in ("base_weight", "spline_weight", "spline_scaler")])
+    assert max_rel(step.flat_grad.cpu(), flat_ref) <= 1e-5

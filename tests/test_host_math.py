@@ -1,0 +1,173 @@
+"""kan_math.h (the inline math every kernel calls) compiled for the host and
+checked against the oracle and the golden fixtures.  No GPU needed."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_state_dict, max_rel
+from oracle import kan_oracle as O
+
+SIGMA, RATE = O.BS_SIGMA, O.BS_RATE
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+@pytest.fixture(scope="session")
+def hm():
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libhostmath.so")
+    src = os.path.join(ROOT, "tests", "host_math.cpp")
+    hdr = os.path.join(ROOT, "pde_amd", "csrc", "kan_math.h")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", src, "-o", lib])
+    return ctypes.CDLL(lib)
+
+
+def fptr(a):
+    return a.ctypes.data_as(FP)
+
+
+def dense_from_local(hm, knots, x, C):
+    """Scatter the 4 live bases (and derivatives) into dense [4][C] rows."""
+    out = np.zeros(16, np.float32)
+    c0, inside = ctypes.c_int(), ctypes.c_int()
+    hm.hm_eval_basis(fptr(knots), len(knots), ctypes.c_float(x), fptr(out), ctypes.byref(c0), ctypes.byref(inside))
+    dense = np.zeros((4, C), np.float64)
+    for m in range(4):
+        c = c0.value + m
+        if 0 <= c < C:
+            dense[:, c] = out[m::4]
+    return dense, inside.value
+
+
+def dense_reference(knots, xs, C, orders=4):
+    """Dense Cox-de Boor in fp64 and its autograd derivatives: [orders][N][C]."""
+    g64 = torch.from_numpy(np.asarray(knots)).double().unsqueeze(0)
+    xt = torch.from_numpy(np.asarray(xs, np.float32)).double().unsqueeze(1).requires_grad_(True)
+    cur = [O.b_splines(xt, g64, 3)[:, 0, c] for c in range(C)]
+    out = [torch.stack(cur, 1)]
+    for _ in range(orders - 1):
+        cur = [torch.autograd.grad(t.sum(), xt, create_graph=True)[0][:, 0] for t in cur]
+        out.append(torch.stack(cur, 1))
+    return torch.stack(out).detach().numpy()
+
+
+@pytest.mark.parametrize("G", [5, 10, 20])
+def test_local_basis_matches_dense_cox_de_boor(hm, G):
+    knots = O.uniform_grid(1, G)[0].numpy().copy()
+    C = G + 3
+    h = 2.0 / G
+    xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 301),
+                         knots.astype(np.float64), [-7.0, 9.0]]).astype(np.float32)
+    ref = dense_reference(knots, xs, C)
+    scale = np.array([1.0, 1 / h, 1 / h ** 2, 1 / h ** 3])[:, None]
+    for n, x in enumerate(xs):
+        dense, inside = dense_from_local(hm, knots, float(x), C)
+        err = np.abs((dense - ref[:, n]) / scale).max()
+        assert err < 5e-6, (float(x), err)
+        assert inside == int(knots[0] <= x < knots[-1])
+
+
+def test_local_basis_nonuniform_knots(hm):
+    rng = np.random.default_rng(0)
+    knots = np.sort(rng.uniform(-2, 2, 12)).astype(np.float32)
+    knots += np.arange(12, dtype=np.float32) * 0.05          # keep them apart
+    xs = rng.uniform(knots[0] - 0.2, knots[-1] + 0.2, 200).astype(np.float32)
+    ref = dense_reference(knots, xs, 8, orders=3)
+    for n, x in enumerate(xs):
+        dense, _ = dense_from_local(hm, knots, float(x), 8)
+        for k in range(3):
+            assert np.abs(dense[k] - ref[k, n]).max() < 1e-5 * max(1.0, np.abs(ref[k]).max())
+
+
+def test_silu_derivatives(hm):
+    out = np.zeros(4, np.float32)
+    for x in np.linspace(-6, 6, 49):
+        hm.hm_eval_act(1, ctypes.c_float(x), fptr(out))
+        xt = torch.tensor(float(np.float32(x)), dtype=torch.float64, requires_grad=True)
+        f0 = torch.nn.functional.silu(xt)
+        f1, = torch.autograd.grad(f0, xt, create_graph=True)
+        f2, = torch.autograd.grad(f1, xt, create_graph=True)
+        f3, = torch.autograd.grad(f2, xt)
+        ref = np.array([f0.item(), f1.item(), f2.item(), f3.item()])
+        assert np.abs(out - ref).max() < 2e-6
+    hm.hm_eval_act(0, ctypes.c_float(0.3), fptr(out))
+    assert np.allclose(out, [0.3, 1, 0, 0])
+
+
+def pack(layer):
+    sw = layer["spline_weight"].numpy()
+    if layer.get("spline_scaler") is not None:
+        sw = sw * layer["spline_scaler"].numpy()[..., None]
+    return np.ascontiguousarray(np.concatenate([sw, layer["base_weight"].numpy()[..., None]], -1), np.float32)
+
+
+def host_step(hm, layers, x, act):
+    """The train step as the kernels compute it, on the host."""
+    N, d = x.shape
+    D, D2 = d, d - 1
+    J = 1 + D + D2
+    actk = {"identity": 0, "silu": 1}[act]
+    jets = np.zeros((N, d, J), np.float32)
+    jets[:, :, 0] = x
+    for i in range(d):
+        jets[:, i, 1 + i] = 1.0
+    acts, packed = [jets], [pack(l) for l in layers]
+    for l, wp in zip(layers, packed):
+        Oo, I = l["base_weight"].shape
+        G = l["spline_weight"].shape[2] - 3
+        y = np.zeros((N, Oo, J), np.float32)
+        grid = np.ascontiguousarray(l["grid"].numpy(), np.float32)
+        assert hm.hm_layer_fwd(D, D2, fptr(acts[-1]), fptr(grid), fptr(wp), fptr(y), ctypes.c_int64(N), I, Oo, G, actk) == 0
+        acts.append(y)
+    v = acts[-1][:, 0, :].astype(np.float64)
+    res = v[:, D] + RATE * v[:, 0]
+    for j in range(D2):
+        res = res - 0.5 * SIGMA ** 2 * x[:, j].astype(np.float64) ** 2 * v[:, 1 + D + j] - RATE * x[:, j] * v[:, 1 + j]
+    loss = (res ** 2).mean()
+    g = 2.0 * res / N
+    gy = np.zeros((N, 1, J), np.float32)
+    gy[:, 0, 0] = g * RATE
+    gy[:, 0, D] = g
+    for j in range(D2):
+        gy[:, 0, 1 + j] = -g * RATE * x[:, j]
+        gy[:, 0, 1 + D + j] = -g * 0.5 * SIGMA ** 2 * x[:, j].astype(np.float64) ** 2
+    grads = [None] * len(layers)
+    for li in range(len(layers) - 1, -1, -1):
+        l, wp = layers[li], packed[li]
+        Oo, I = l["base_weight"].shape
+        G = l["spline_weight"].shape[2] - 3
+        ga = np.zeros((N, I, J), np.float32)
+        gw = np.zeros_like(wp)
+        grid = np.ascontiguousarray(l["grid"].numpy(), np.float32)
+        assert hm.hm_layer_bwd(D, D2, fptr(acts[li]), fptr(gy), fptr(grid), fptr(wp), fptr(ga), fptr(gw),
+                               ctypes.c_int64(N), I, Oo, G, actk) == 0
+        sw, sc = l["spline_weight"].numpy(), l["spline_scaler"].numpy()
+        grads[li] = {"base_weight": gw[..., -1], "spline_weight": gw[..., :-1] * sc[..., None],
+                     "spline_scaler": (gw[..., :-1] * sw).sum(-1)}
+        gy = ga
+    return {"v": v[:, 0], "first": v[:, 1:1 + D], "second": v[:, 1 + D:], "res": res, "loss": loss, "grads": grads}
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg1_identity", "cfg2_silu", "cfg4_narrow", "cfg5_narrow",
+                                  "updated_grid", "deeponet_trunk"])
+def test_host_step_matches_reference(hm, golden, case):
+    rec = golden(case)
+    layers = O.layers_from_state_dict(golden_state_dict(rec))
+    out = host_step(hm, layers, rec["x"], str(rec["act"]))
+    tol = 1e-5
+    assert max_rel(out["v"], rec["v64"]) <= tol
+    assert max_rel(out["first"], rec["first64"]) <= tol
+    assert max_rel(out["second"], rec["second64"]) <= tol
+    assert max_rel(out["res"], rec["res64"]) <= tol
+    assert max_rel(out["loss"], rec["loss64"]) <= tol
+    for l, g in enumerate(out["grads"]):
+        for key, val in g.items():
+            r64, r32 = rec[f"grad64.layers.{l}.{key}"], rec[f"grad.layers.{l}.{key}"]
+            assert max_rel(val, r64) <= tol, (l, key)
+            # against the fp32 reference allow that reference's own fp32 noise on top
+            assert max_rel(val, r32) <= tol + max_rel(r32, r64), (l, key)
