@@ -1,13 +1,457 @@
-// Dense f32-MFMA path for wide hidden layers (placeholder: not yet enabled).
+// Dense fp32-MFMA path for wide hidden KAN layers on gfx950, J = 4 jets per
+// scalar (value, d/dS, d/dt, d2/dS2).
+//
+// With the 4 jets of a point stacked as 4 matrix rows, one layer is three
+// GEMM-shaped contractions over K = in_features * C1 expanded basis columns
+// (C1 = G+3 spline bases + 1 base-activation column per input feature):
+//   forward        Y [4N x O]  = E [4N x K] * W^T [K x O]
+//   input grads    gE[4N x K]  = gY[4N x O] * W   [O x K]   (+ chain rule through the basis)
+//   weight grads   gW[K x O]   = E^T[K x 4N] * gY [4N x O]
+// E is never stored: every kernel rebuilds the slab of E it needs from the
+// 16-byte input jet of a (point, feature) with a few dozen VALU ops, parks it
+// in LDS in MFMA operand order, and the matrix cores do the rest in exact fp32
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: an fmaf chain, no reduced
+// precision).  Only 4 of the G+3 spline columns of a feature are non-zero for
+// a given point, so the E tile is zero-filled and 4+1 columns are overwritten.
+//
+// C/D register maps used below (dtype independent on gfx950):
+//   32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+//   16x16: col = lane&15, row = 4*(lane>>4) + reg
+// so a lane always owns 4 consecutive rows = the 4 jets of one point.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "kan_math.h"
 #include "kan_launch.h"
 
 namespace pdekan {
 
-bool mfma_eligible(int, int, const LayerView&) { return false; }
-int mfma_weight_chunks(int64_t, const LayerView&) { return 1; }
-void launch_fwd_mfma(const LayerView&, const float*, const float*, float*, int64_t, hipStream_t) {}
-void launch_bwd_input_mfma(const LayerView&, const float*, const float*, const float*, float*, int64_t, hipStream_t) {}
-void launch_bwd_weight_mfma(const LayerView&, const float*, const float*, float*, int, int64_t, hipStream_t) {}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKnotPad = 28;   // >= G+7 for G <= 21
+
+// ---- expanded basis jets of one (point, feature) -------------------------
+// e[m] (m<4): jets of spline column c0+m ; e[4]: jets of the base-activation column
+__device__ __forceinline__ void expand_jets(const float* knots, int nk, int act, float4 jet,
+                                            float4 (&e)[5], int& c0) {
+  Basis bs;
+  eval_basis<false>(knots, nk, jet.x, bs);
+  const Act av = eval_act(act, jet.x);
+  const float s2 = jet.y * jet.y;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    e[m] = make_float4(bs.b[m], bs.d1[m] * jet.y, bs.d1[m] * jet.z, bs.d2[m] * s2 + bs.d1[m] * jet.w);
+  e[4] = make_float4(av.f0, av.f1 * jet.y, av.f1 * jet.z, av.f2 * s2 + av.f1 * jet.w);
+  c0 = bs.c0;
+}
+
+// Write one feature's C1 columns of the E tile, layout tile[col][RS] with the 4
+// jets of local point p at [col][4p .. 4p+3] (one 16-byte store per column).
+template <int C1>
+__device__ __forceinline__ void write_expanded(float* tile, int RS, int f_local, int p_local,
+                                               const float4 (&e)[5], int c0) {
+  constexpr int C = C1 - 1;
+  float* base = tile + (f_local * C1) * RS + p_local * 4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(base + c * RS) = zero;
+  *reinterpret_cast<float4*>(base + C * RS) = e[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = c0 + m;
+    if (c >= 0 && c < C) *reinterpret_cast<float4*>(base + c * RS) = e[m];
+  }
+}
+
+// ==========================================================================
+// forward:  block = 4 waves, 64 points x 64 outputs; wave = 16 points (64 rows)
+// K is walked in slabs of KI features (KK = KI*C1 columns, even).
+// ==========================================================================
+template <int C1, int KI>
+__global__ void __launch_bounds__(256, 2)
+fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ wt,
+                float4* __restrict__ y, int64_t N, int I, int O, int act) {
+  constexpr int KK = KI * C1;
+  static_assert(KK % 2 == 0, "k-step of 2");
+  constexpr int nk = C1 + 3;               // G + 7
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sW = reinterpret_cast<float*>(smem);            // [KK][64]
+  float* sA = sW + KK * 64;                              // [4][KK][64]
+  float* sK = sA + 4 * KK * 64;                          // [KI][kKnotPad]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int p_local = lane & 15, f_local = lane >> 4;
+  const int64_t P0 = (int64_t)blockIdx.x * 64 + wave * 16;
+  const int o0 = blockIdx.y * 64;
+  float* tileA = sA + wave * KK * 64;
+  const int h = lane >> 5, r = lane & 31;
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+  for (int i0 = 0; i0 < I; i0 += KI) {
+    __syncthreads();                                     // previous slab fully consumed
+    for (int idx = tid; idx < KK * 16; idx += 256) {
+      const int kk = idx >> 4, c4 = idx & 15;
+      const float4 v = *reinterpret_cast<const float4*>(wt + (size_t)(i0 * C1 + kk) * O + o0 + c4 * 4);
+      *reinterpret_cast<float4*>(sW + kk * 64 + c4 * 4) = v;
+    }
+    for (int idx = tid; idx < KI * nk; idx += 256) {
+      const int f = idx / nk, k = idx - f * nk;
+      sK[f * kKnotPad + k] = grid[(size_t)(i0 + f) * nk + k];
+    }
+    __syncthreads();
+    if (f_local < KI) {
+      int64_t p = P0 + p_local;
+      if (p > N - 1) p = N - 1;
+      const float4 jet = a[p * I + i0 + f_local];
+      float4 e[5];
+      int c0;
+      expand_jets(sK + f_local * kKnotPad, nk, act, jet, e, c0);
+      write_expanded<C1>(tileA, 64, f_local, p_local, e, c0);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int t = 0; t < KK / 2; ++t) {
+      const int kk = 2 * t + h;
+      const float a0 = tileA[kk * 64 + r], a1 = tileA[kk * 64 + 32 + r];
+      const float b0 = sW[kk * 64 + r], b1 = sW[kk * 64 + 32 + r];
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+    }
+  }
+  // rows 8g+4h .. +3 of an m-tile are the 4 jets of local point 2g+h (+8 per m-tile)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t pa = P0 + 2 * g + h, pb = pa + 8;
+    if (pa < N) {
+      y[(pa * O + o0 + r)] = make_float4(acc00[4 * g], acc00[4 * g + 1], acc00[4 * g + 2], acc00[4 * g + 3]);
+      y[(pa * O + o0 + 32 + r)] = make_float4(acc01[4 * g], acc01[4 * g + 1], acc01[4 * g + 2], acc01[4 * g + 3]);
+    }
+    if (pb < N) {
+      y[(pb * O + o0 + r)] = make_float4(acc10[4 * g], acc10[4 * g + 1], acc10[4 * g + 2], acc10[4 * g + 3]);
+      y[(pb * O + o0 + 32 + r)] = make_float4(acc11[4 * g], acc11[4 * g + 1], acc11[4 * g + 2], acc11[4 * g + 3]);
+    }
+  }
+}
+
+// ==========================================================================
+// weight gradients: block = 4 waves; wave w owns KIW features (cols = KIW*C1,
+// a multiple of 16) x 64 outputs of accumulators and the block walks its chunk
+// of points PB at a time.  D[i = column][j = output] += E[row][column] * gY[row][output],
+// one 16x16x4 MFMA reduces over the 4 jets of one point.
+// Output: part[chunk][O][I][C1] (summed over chunks by reduce_unpack).
+// ==========================================================================
+template <int C1, int KIW>
+__global__ void __launch_bounds__(256, 2)
+bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
+                       const float* __restrict__ grid, float* __restrict__ part,
+                       int64_t N, int I, int O, int act, int64_t chunk_pts) {
+  constexpr int COLS = KIW * C1;
+  static_assert(COLS % 16 == 0, "16-wide column tiles");
+  constexpr int NT = COLS / 16;
+  constexpr int PB = 64 / KIW;             // points per pass: one (point, feature) per lane
+  constexpr int ROWS = PB * 4;
+  constexpr int RS = ROWS + 4;             // E tile row stride (16-byte aligned, not a multiple of 32)
+  constexpr int RG = 80;                   // gY tile row stride: quarter-waves land on disjoint banks
+  constexpr int nk = C1 + 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sE = reinterpret_cast<float*>(smem);            // [4][COLS][RS]
+  float* sG = sE + 4 * COLS * RS;                        // [ROWS][RG]
+  float* sK = sG + ROWS * RG;                            // [4*KIW][kKnotPad]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int p_local = lane % PB, f_local = lane / PB;
+  const int i0 = (blockIdx.x * 4 + wave) * KIW;
+  const int o0 = blockIdx.y * 64;
+  float* tileE = sE + wave * COLS * RS;
+  const int q = lane >> 4, l15 = lane & 15;
+
+  for (int idx = tid; idx < 4 * KIW * nk; idx += 256) {
+    const int f = idx / nk, k = idx - f * nk;
+    sK[f * kKnotPad + k] = grid[(size_t)(blockIdx.x * 4 * KIW + f) * nk + k];
+  }
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t pbeg = (int64_t)blockIdx.z * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  for (int64_t pb = pbeg; pb < pend; pb += PB) {
+    __syncthreads();                                     // previous pass consumed (and knots visible)
+    for (int idx = tid; idx < PB * 64; idx += 256) {
+      const int p = idx >> 6, o = idx & 63;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pb + p < pend) v = gy[(pb + p) * O + o0 + o];
+      float* dst = sG + (p * 4) * RG + o;
+      dst[0] = v.x; dst[RG] = v.y; dst[2 * RG] = v.z; dst[3 * RG] = v.w;
+    }
+    {
+      int64_t p = pb + p_local;
+      if (p > N - 1) p = N - 1;
+      const float4 jet = a[p * I + i0 + f_local];
+      float4 e[5];
+      int c0;
+      expand_jets(sK + (wave * KIW + f_local) * kKnotPad, nk, act, jet, e, c0);
+      write_expanded<C1>(tileE, RS, f_local, p_local, e, c0);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int t = 0; t < PB; ++t) {
+      float b[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) b[m] = sG[(4 * t + q) * RG + m * 16 + l15];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float av = tileE[(n * 16 + l15) * RS + 4 * t + q];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[m], acc[n][m], 0, 0, 0);
+      }
+    }
+  }
+  // D[i = column][j = output]: this lane holds columns n*16 + 4q + reg of output m*16 + l15
+  const int C1r = C1;
+  float* dst0 = part + ((size_t)blockIdx.z * O + o0) * I * C1r + (size_t)i0 * C1r;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float* dst = dst0 + (size_t)(m * 16 + l15) * I * C1r + n * 16 + 4 * q;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[rg] = acc[n][m][rg];
+    }
+}
+
+// ==========================================================================
+// input-jet gradients: block = 4 waves x 8 points.  Per slab of KIS features
+//   gE[row][column] = sum_o gY[row][o] * W[o][column]       (16x16x4 MFMA, A = gY kept in registers)
+// then each (point, feature) lane pulls its 4+1 live columns out of LDS and
+// applies the chain rule through B', B'', B''' and the activation derivatives.
+// ==========================================================================
+template <int C1, int KIS, int OT>
+__global__ void __launch_bounds__(256, 2)
+bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
+                      const float* __restrict__ grid, const float* __restrict__ wp,
+                      float4* __restrict__ ga, int64_t N, int I, int O, int act) {
+  constexpr int C = C1 - 1;
+  constexpr int COLS = KIS * C1;
+  static_assert(COLS % 16 == 0, "16-wide column tiles");
+  constexpr int NT = COLS / 16;
+  constexpr int RW = COLS + ((COLS % 32 == 16) ? 0 : 16);   // W slab row stride = 16 mod 32
+  constexpr int RT = 66;                                  // gY staging row stride
+  constexpr int nk = C1 + 3;
+  constexpr int S_FLOATS = 4 * 8 * COLS * 4;              // per-wave [8 points][COLS][4 jets]
+  constexpr int W_FLOATS = 64 * RW;
+  constexpr int T_FLOATS = 128 * RT;
+  constexpr int U_FLOATS = (S_FLOATS > W_FLOATS ? (S_FLOATS > T_FLOATS ? S_FLOATS : T_FLOATS)
+                                                : (W_FLOATS > T_FLOATS ? W_FLOATS : T_FLOATS));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sU = reinterpret_cast<float*>(smem);             // union: gY staging / W slab / gE tiles
+  float* sK = sU + U_FLOATS;                              // [KIS][kKnotPad]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int64_t PB0 = (int64_t)blockIdx.x * 32;           // block's first point
+  const int64_t PW0 = PB0 + wave * 8;                     // wave's first point
+
+  // ---- gY of this wave's 32 rows into registers, 64 outputs at a time ----
+  float afrag[OT][2][16];
+#pragma unroll
+  for (int oc = 0; oc < OT; ++oc) {
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 64; idx += 256) {
+      const int p = idx >> 6, o = idx & 63;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PB0 + p < N) v = gy[(PB0 + p) * O + oc * 64 + o];
+      float* dst = sU + (p * 4) * RT + o;
+      dst[0] = v.x; dst[RT] = v.y; dst[2 * RT] = v.z; dst[3 * RT] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) afrag[oc][mt][t] = sU[(wave * 32 + mt * 16 + l15) * RT + 4 * t + q];
+  }
+
+  for (int i0 = 0; i0 < I; i0 += KIS) {
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[mt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int oc = 0; oc < OT; ++oc) {
+      __syncthreads();                                    // union region free again
+      for (int idx = tid; idx < 64 * (COLS / 4); idx += 256) {
+        const int o = idx / (COLS / 4), c4 = idx - o * (COLS / 4);
+        const float4 v = *reinterpret_cast<const float4*>(wp + ((size_t)(oc * 64 + o) * I + i0) * C1 + c4 * 4);
+        *reinterpret_cast<float4*>(sU + o * RW + c4 * 4) = v;
+      }
+      if (oc == 0)
+        for (int idx = tid; idx < KIS * nk; idx += 256) {
+          const int f = idx / nk, k = idx - f * nk;
+          sK[f * kKnotPad + k] = grid[(size_t)(i0 + f) * nk + k];
+        }
+      __syncthreads();
+#pragma unroll 4
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float bv = sU[(4 * t + q) * RW + n * 16 + l15];
+          acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[oc][0][t], bv, acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[oc][1][t], bv, acc[1][n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                      // every wave is done with the W slab
+    float4* sS = reinterpret_cast<float4*>(sU) + wave * 8 * COLS;     // [8][COLS] float4
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        sS[(mt * 4 + q) * COLS + n * 16 + l15] = make_float4(acc[mt][n][0], acc[mt][n][1], acc[mt][n][2], acc[mt][n][3]);
+    __syncthreads();
+    for (int pair = lane; pair < 8 * KIS; pair += 64) {
+      const int p_local = pair & 7, f_local = pair >> 3;
+      const int64_t p = PW0 + p_local;
+      if (p < N) {
+        const float4 jet = a[p * I + i0 + f_local];
+        Basis bs;
+        eval_basis<true>(sK + f_local * kKnotPad, nk, jet.x, bs);
+        const Act av = eval_act(act, jet.x);
+        const float4* col = sS + p_local * COLS + f_local * C1;
+        const float s2 = jet.y * jet.y;
+        float ox = 0.f, oy = 0.f, oz = 0.f, ow = 0.f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          float e1, e2, e3;
+          float4 g;
+          if (m < 4) {
+            const int c = bs.c0 + m;
+            const bool ok = (c >= 0) && (c < C);
+            g = ok ? col[ok ? c : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            e1 = bs.d1[m & 3]; e2 = bs.d2[m & 3]; e3 = bs.d3[m & 3];
+          } else {
+            g = col[C];
+            e1 = av.f1; e2 = av.f2; e3 = av.f3;
+          }
+          ox += g.x * e1 + (g.y * jet.y + g.z * jet.z) * e2 + g.w * (s2 * e3 + jet.w * e2);
+          oy += g.y * e1 + 2.0f * jet.y * g.w * e2;
+          oz += g.z * e1;
+          ow += g.w * e1;
+        }
+        ga[p * I + i0 + f_local] = make_float4(ox, oy, oz, ow);
+      }
+    }
+  }
+}
+
+// ==========================================================================
+// host side
+// ==========================================================================
+struct MfmaCfg { int ki_fwd, kiw, kis; };
+
+static bool cfg_for(int G, MfmaCfg& c) {
+  if (G == 10) { c = {4, 8, 8}; return true; }
+  if (G == 20) { c = {2, 4, 4}; return true; }
+  if (G == 5) { c = {4, 16, 16}; return true; }
+  return false;
+}
+
+bool mfma_eligible(int D, int D2, const LayerView& L) {
+  if (D != 2 || D2 != 1) return false;
+  const char* off = getenv("PDEKAN_DISABLE_MFMA");      // A/B switch for tests and profiling
+  if (off && off[0] == '1') return false;
+  MfmaCfg c;
+  if (!cfg_for(L.G, c)) return false;
+  if (L.O % 64 != 0 || L.O > 256 || L.O == 192) return false;
+  if (L.I < 32 || L.I % (4 * c.kiw) != 0) return false;
+  return true;
+}
+
+int mfma_weight_chunks(int64_t N, const LayerView& L) {
+  MfmaCfg c;
+  cfg_for(L.G, c);
+  const int per_chunk = (L.I / (4 * c.kiw)) * (L.O / 64);
+  int64_t want = (512 + per_chunk - 1) / per_chunk;
+  const int64_t cap = (N + 511) / 512;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+template <typename Kern>
+static void allow_big_lds(Kern k, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int C1, int KI>
+static void fwd_launch(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
+  constexpr int KK = KI * C1;
+  const size_t lds = (size_t)(5 * KK * 64 + KI * kKnotPad) * 4;
+  auto k = fwd_mfma_kernel<C1, KI>;
+  allow_big_lds(k, lds);
+  dim3 g((unsigned)((N + 63) / 64), L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), L.grid, wt, reinterpret_cast<float4*>(y), N, L.I, L.O, L.act);
+}
+
+void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
+  if (L.G == 10) fwd_launch<14, 4>(L, a, wt, y, N, st);
+  else if (L.G == 20) fwd_launch<24, 2>(L, a, wt, y, N, st);
+  else fwd_launch<9, 4>(L, a, wt, y, N, st);
+}
+
+template <int C1, int KIW>
+static void bww_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
+                       hipStream_t st) {
+  constexpr int COLS = KIW * C1, PB = 64 / KIW, ROWS = PB * 4, RS = ROWS + 4;
+  const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
+  int64_t chunk = (N + nchunks - 1) / nchunks;
+  chunk = (chunk + PB - 1) / PB * PB;
+  auto k = bwd_weight_mfma_kernel<C1, KIW>;
+  allow_big_lds(k, lds);
+  dim3 g(L.I / (4 * KIW), L.O / 64, nchunks);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy), L.grid, part, N, L.I,
+                         L.O, L.act, chunk);
+}
+
+void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
+                            hipStream_t st) {
+  if (L.G == 10) bww_launch<14, 8>(L, a, gy, part, nchunks, N, st);
+  else if (L.G == 20) bww_launch<24, 4>(L, a, gy, part, nchunks, N, st);
+  else bww_launch<9, 16>(L, a, gy, part, nchunks, N, st);
+}
+
+template <int C1, int KIS, int OT>
+static void bwi_launch(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga, int64_t N,
+                       hipStream_t st) {
+  constexpr int COLS = KIS * C1;
+  constexpr int RW = COLS + ((COLS % 32 == 16) ? 0 : 16);
+  constexpr int S = 4 * 8 * COLS * 4, W = 64 * RW, T = 128 * 66;
+  constexpr int U = (S > W ? (S > T ? S : T) : (W > T ? W : T));
+  const size_t lds = (size_t)(U + KIS * kKnotPad) * 4;
+  auto k = bwd_input_mfma_kernel<C1, KIS, OT>;
+  allow_big_lds(k, lds);
+  k<<<(unsigned)((N + 31) / 32), 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy),
+                                                 L.grid, wp, reinterpret_cast<float4*>(ga), N, L.I, L.O, L.act);
+}
+
+template <int C1, int KIS>
+static void bwi_dispatch(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga, int64_t N,
+                         hipStream_t st) {
+  if (L.O == 64) bwi_launch<C1, KIS, 1>(L, a, gy, wp, ga, N, st);
+  else if (L.O == 128) bwi_launch<C1, KIS, 2>(L, a, gy, wp, ga, N, st);
+  else bwi_launch<C1, KIS, 4>(L, a, gy, wp, ga, N, st);
+}
+
+void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga, int64_t N,
+                           hipStream_t st) {
+  if (L.G == 10) bwi_dispatch<14, 8>(L, a, gy, wp, ga, N, st);
+  else if (L.G == 20) bwi_dispatch<24, 4>(L, a, gy, wp, ga, N, st);
+  else bwi_dispatch<9, 16>(L, a, gy, wp, ga, N, st);
+}
 
 }  // namespace pdekan

@@ -167,3 +167,62 @@ def test_large_batch_properties():
     flat_ref = torch.cat([ref["grads"][l][k].flatten() for l in range(3)
                           for k in ("base_weight", "spline_weight", "spline_scaler")])
     assert max_rel(step.flat_grad.cpu(), flat_ref) <= 1e-5
+
+
+def _random_model(widths, G, seed, act=torch.nn.SiLU):
+    from pde_amd import KAN
+    torch.manual_seed(seed)
+    m = KAN(widths, grid_size=G, base_activation=act)
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    return m
+
+
+@pytest.mark.parametrize("G,N", [(10, 1), (10, 63), (10, 65), (10, 1500), (5, 777), (20, 500)])
+def test_mfma_hidden_layer_step_matches_oracle(G, N):
+    """[2,64,64,1]: the 64x64 layer takes the MFMA kernels (forward, input
+    gradients, weight gradients); ragged N exercises the tile tails and several
+    point chunks."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model([2, 64, 64, 1], G, 11 + G)
+    layers = O.layers_from_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    x = torch.rand(N, 2, generator=torch.Generator().manual_seed(5))
+    ref = O.pinn_step(x, layers, "silu")
+    ref64 = O.pinn_step(x.double(), O.layers_from_state_dict(m.state_dict(), dtype=torch.float64), "silu")
+    m = m.cuda()
+    step = BlackScholesStep(m)
+    res = torch.empty(N, device="cuda")
+    loss = step(x.cuda(), residual_out=res).item()
+    flat32 = torch.cat([ref["grads"][l][k].flatten() for l in range(3)
+                        for k in ("base_weight", "spline_weight", "spline_scaler")])
+    flat64 = torch.cat([ref64["grads"][l][k].flatten() for l in range(3)
+                        for k in ("base_weight", "spline_weight", "spline_scaler")])
+    assert max_rel(res.cpu(), ref64["res"]) <= TOL
+    assert abs(loss - ref64["loss"].item()) <= TOL * abs(ref64["loss"].item())
+    assert max_rel(step.flat_grad.cpu(), flat64) <= TOL
+    assert max_rel(step.flat_grad.cpu(), flat32) <= TOL + max_rel(flat32, flat64)
+    # per-layer too: a wrong small tensor must not hide behind a large one
+    off = 0
+    for l in range(3):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            n = ref64["grads"][l][k].numel()
+            assert max_rel(step.flat_grad[off:off + n].cpu(), ref64["grads"][l][k].flatten()) <= TOL, (l, k)
+            off += n
+
+
+def test_mfma_and_streaming_paths_agree(monkeypatch):
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model([2, 64, 64, 1], 10, 3).cuda()
+    x = torch.rand(4099, 2, generator=torch.Generator().manual_seed(9)).cuda()
+    step = BlackScholesStep(m)
+    l_mfma = step(x).item()
+    g_mfma = step.flat_grad.clone()
+    monkeypatch.setenv("PDEKAN_DISABLE_MFMA", "1")
+    step = BlackScholesStep(m)          # workspace size depends on the path
+    l_gen = step(x).item()
+    g_gen = step.flat_grad.clone()
+    monkeypatch.delenv("PDEKAN_DISABLE_MFMA")
+    assert abs(l_mfma - l_gen) <= 2e-6 * abs(l_gen)
+    assert max_rel(g_mfma.cpu(), g_gen.cpu()) <= 5e-6
