@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark: collocation points per second of one KAN-PINN train step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+
+One step = forward with analytic input derivatives + Black-Scholes residual +
+mean-squared loss + backward to every parameter gradient (one call into
+libpdekan.so), + gradient all-reduce over RCCL when N > 1, + an AdamW update.
+Points and weights are synthetic (seeded), resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  cfg1  KAN [2,5,1]            grid 5   10^4 points
+  cfg2  KAN [2,64,64,1]        grid 10  2^20 points per GPU   (default at --gpus 1)
+  cfg3  = cfg2 sharded, 2^24 points over 8 GPUs -> 2^21 per GPU (default at --gpus > 1)
+  cfg4  KAN [2,256,256,256,1]  grid 20  2^22 points in total
+  cfg5  KAN [6,128,128,1]      grid 10  2^22 points in total, 5 assets + time
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # dense fp32 matrix peak of MI355X (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+WORKLOADS = {
+    "cfg1": dict(widths=[2, 5, 1], grid=5, pts_per_gpu=10_000),
+    "cfg2": dict(widths=[2, 64, 64, 1], grid=10, pts_per_gpu=1 << 20),
+    "cfg3": dict(widths=[2, 64, 64, 1], grid=10, pts_per_gpu=1 << 21),
+    "cfg4": dict(widths=[2, 256, 256, 256, 1], grid=20, pts_total=1 << 22),
+    "cfg5": dict(widths=[6, 128, 128, 1], grid=10, pts_total=1 << 22),
+}
+CPU_SAMPLE = {"cfg1": 10_000, "cfg2": 1 << 14, "cfg3": 1 << 14, "cfg4": 1 << 10, "cfg5": 1 << 12}
+
+
+def kernel_cost(name, widths, grid, n_pts, J):
+    """Algorithmic work of one launch of kernel `name` on n_pts points:
+    (flops, bytes).  flops: the dense contraction 2*J*I*(C+1)*O per point;
+    bytes: jets read and written, fp32, each tensor once."""
+    C1 = grid + 4
+    if not name.startswith("L"):
+        if name == "bs_residual_loss":
+            return 0.0, n_pts * 4.0 * (2 * J + widths[0])
+        if name == "seed_jets":
+            return 0.0, n_pts * 4.0 * widths[0] * (1 + J)
+        return 0.0, 0.0
+    layer = int(name[1:name.index(".")])
+    I, O = widths[layer], widths[layer + 1]
+    kind = name.split(".")[1]
+    flops = 2.0 * J * I * C1 * O * n_pts
+    if kind == "fwd":
+        byts = 4.0 * J * (I + O) * n_pts
+    elif kind == "bwd_input":
+        byts = 4.0 * J * (2 * I + O) * n_pts
+    elif kind == "bwd_weight":
+        byts = 4.0 * J * (I + O) * n_pts
+    else:                                   # reduce_unpack: O(parameters)
+        return 0.0, 0.0
+    return flops, byts
+
+
+def cpu_baseline(name, model_sd, widths, act, steps=2):
+    """The reference algorithm (dense Cox-de Boor + F.linear + nested autograd)
+    on the host cores, on a bounded sample of the same workload."""
+    from oracle import kan_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    n = CPU_SAMPLE[name]
+    x = torch.rand(n, widths[0], generator=torch.Generator().manual_seed(0))
+    layers = O.layers_from_state_dict(model_sd)
+    O.pinn_step(x[: max(256, n // 8)], layers, act)       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.pinn_step(x, layers, act)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of {n} points of the same model and point distribution, "
+                      f"{dt:.2f} s/step, PyTorch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip the AdamW update")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pde_amd import KAN, _lib
+    from pde_amd.dist import DataParallelStep
+    from pde_amd.pinn import BlackScholesStep
+
+    name = args.workload or ("cfg2" if world == 1 else "cfg3")
+    wl = WORKLOADS[name]
+    widths, grid = wl["widths"], wl["grid"]
+    n_local = wl["pts_per_gpu"] if "pts_per_gpu" in wl else wl["pts_total"] // world
+    n_global = n_local * world
+    d = widths[0]
+    J = 2 * d
+
+    torch.manual_seed(0)                                   # reference-compatible seeded init
+    model = KAN(widths, grid_size=grid).to(dev)
+    # the same global point set whatever the rank count: rank r takes the r-th contiguous shard
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(n_local, d, generator=gen).to(dev)
+
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    step = BlackScholesStep(model, micro_batch=args.micro_batch)
+    dp = DataParallelStep(step, dist) if world > 1 else None
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01)   # run1.py:209
+
+    def one_step():
+        if dp is not None:
+            loss = dp(x, n_global=n_global)
+        else:
+            loss = step(x)
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_global * args.steps / elapsed
+    loss_val = float(loss.item())
+
+    # ---- per-kernel timing of the same step (HIP events on the launch stream) ----
+    lib = _lib.load()
+    prof_steps = 3
+    lib.pdekan_profile_begin()
+    for _ in range(prof_steps):
+        step(x, n_global=n_global)
+    torch.cuda.synchronize()
+    lib.pdekan_profile_end()
+    prof = _lib.profile_results()
+    n_launch_pts = n_local if args.micro_batch <= 0 else min(args.micro_batch, n_local)
+    kernels = {}
+    for kname, (ms, cnt) in prof.items():
+        fl, by = kernel_cost(kname, widths, grid, n_launch_pts, J)
+        kernels[kname] = {"avg_ms": ms / cnt, "launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
+                          "flops": fl, "bytes": by}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    kd = kernels[dom]
+    if dom.endswith(".mfma"):
+        ach = kd["flops"] / (kd["avg_ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
+                "algorithmic_flops_per_launch": kd["flops"]}
+    else:
+        ach = kd["bytes"] / (kd["avg_ms"] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
+                "algorithmic_bytes_per_launch": kd["bytes"]}
+    step_flops = sum(k["flops"] * k["launches_per_step"] for k in kernels.values())
+    kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
+
+    out = {
+        "metric": "collocation pts/s per KAN-PINN train step",
+        "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}: KAN {widths} grid={grid} k=3 SiLU, Black-Scholes PINN step "
+                               f"(fwd + residual + loss + bwd + AdamW), {n_local} points/GPU, {n_global} total",
+                   "points_per_gpu": n_local, "points_total": n_global, "micro_batch": args.micro_batch,
+                   "optimizer_in_step": not args.no_optimizer, "parallelism": f"dp{world}"},
+        "loss": loss_val,
+        "roofline": roof,
+        "step_dense_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+        "kernel_ms_per_step": kernel_ms,
+        "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
+                    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        act = "silu"
+        out["cpu_baseline"] = cpu_baseline(name, sd0, widths, act)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

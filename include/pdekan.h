@@ -114,6 +114,18 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
                    float rate, float* loss_out, float* res_out, const PdekanLayerGrad* grads,
                    int32_t accumulate, int64_t micro_batch, void* ws, size_t ws_bytes, void* stream);
 
+/* Optional per-kernel timing for benchmarks (no counterpart in the reference,
+ * which only prints a whole-script wall time, run1.py:524-526).  Between
+ * begin and end every kernel launched by the calls above is bracketed by HIP
+ * events on the launch stream; end waits for them and sums the durations per
+ * kernel name ("L1.fwd.mfma", "L0.bwd_weight.stream", "bs_residual_loss" ...).
+ * The bracketing events serialise nothing but cost a little: do not time a
+ * step with profiling on.  Not thread-safe; one profiling session at a time. */
+int pdekan_profile_begin(void);
+int pdekan_profile_end(void);
+int pdekan_profile_count(void);
+int pdekan_profile_entry(int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,11 @@ SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.POINTER(PdekanLayerGrad), ctypes.c_int32,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "pdekan_profile_begin": (ctypes.c_int, []),
+    "pdekan_profile_end": (ctypes.c_int, []),
+    "pdekan_profile_count": (ctypes.c_int, []),
+    "pdekan_profile_entry": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -92,6 +97,19 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def profile_results():
+    """Per-kernel totals gathered between pdekan_profile_begin/end:
+    ``{name: (total_ms, launches)}``."""
+    lib = load()
+    out = {}
+    for i in range(lib.pdekan_profile_count()):
+        name = ctypes.create_string_buffer(64)
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        check(lib.pdekan_profile_entry(i, name, 64, ctypes.byref(ms), ctypes.byref(cnt)))
+        out[name.value.decode()] = (ms.value, cnt.value)
+    return out
 
 
 def check(rc: int) -> None:

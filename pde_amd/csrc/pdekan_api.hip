@@ -27,6 +27,27 @@ int check_launch(const char* what) {
   return PDEKAN_OK;
 }
 
+// ---- optional per-kernel timing (HIP events on the launch stream) ----------
+struct ProfRec { char name[48]; hipEvent_t a, b; };
+struct ProfSum { char name[48]; double ms; long long launches; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<ProfSum> g_prof_sums;
+
+struct ProfScope {
+  hipStream_t st; int idx = -1;
+  ProfScope(hipStream_t s, const char* fmt, int layer) : st(s) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    snprintf(r.name, sizeof(r.name), fmt, layer);
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof_recs.push_back(r);
+    idx = (int)g_prof_recs.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof_recs[idx].b, st); }
+};
+
 bool jet_supported(int d, int d2) { return (d == 0 && d2 == 0) || (d == 2 && d2 == 1) || (d == 6 && d2 == 5); }
 
 int to_view(const PdekanLayer* l, pdekan::LayerView& v) {
@@ -68,32 +89,47 @@ size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
 }
 
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, float* y, int64_t n,
-                hipStream_t st) {
+                hipStream_t st, int li = 0) {
   if (pdekan::mfma_eligible(D, D2, L)) {
+    ProfScope ps(st, "L%d.fwd.mfma", li);
     pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
-  } else if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st)) {
-    return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+  } else {
+    ProfScope ps(st, "L%d.fwd.stream", li);
+    if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st))
+      return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
   }
   return check_launch("layer forward");
 }
 
 int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* gy, const float* wp,
-                 float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st) {
+                 float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st,
+                 int li = 0) {
   const bool mf = pdekan::mfma_eligible(D, D2, L);
   if (g) {
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
       return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
     const int nch = weight_chunks(D, D2, L, n);
-    if (mf) pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st);
-    else if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st))
-      return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+    if (mf) {
+      ProfScope ps(st, "L%d.bwd_weight.mfma", li);
+      pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st);
+    } else {
+      ProfScope ps(st, "L%d.bwd_weight.stream", li);
+      if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st))
+        return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+    }
+    ProfScope ps(st, "L%d.reduce_unpack", li);
     pdekan::launch_reduce_unpack(L, part, nch, g->base_weight, g->spline_weight,
                                  L.scaler ? g->spline_scaler : nullptr, accumulate, st);
   }
   if (ga) {
-    if (mf) pdekan::launch_bwd_input_mfma(L, a, gy, wp, ga, n, st);
-    else if (!pdekan::launch_bwd_input_generic(D, D2, L, a, gy, wp, ga, n, st))
-      return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+    if (mf) {
+      ProfScope ps(st, "L%d.bwd_input.mfma", li);
+      pdekan::launch_bwd_input_mfma(L, a, gy, wp, ga, n, st);
+    } else {
+      ProfScope ps(st, "L%d.bwd_input.stream", li);
+      if (!pdekan::launch_bwd_input_generic(D, D2, L, a, gy, wp, ga, n, st))
+        return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
+    }
   }
   return check_launch("layer backward");
 }
@@ -246,7 +282,7 @@ int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const 
     pdekan::launch_seed_jets(P.D, P.D2, x + p0 * stride_n, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out_jet + p0 * out_w * P.J : W.act[l + 1];
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], dst, m, st);
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], dst, m, st, l);
       if (rc) return rc;
     }
   }
@@ -271,29 +307,38 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
   const float inv_n = 1.0f / (float)n_global;
-  for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+  {
+    ProfScope ps(st, "pack_weights", 0);
+    for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+  }
   bool first = true;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
     const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
     const float* xs = x + p0 * stride_n;
-    pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    {
+      ProfScope ps(st, "seed_jets", 0);
+      pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    }
     for (int l = 0; l < nl; ++l) {
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.act[l + 1], m, st);
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.act[l + 1], m, st, l);
       if (rc) return rc;
     }
     int nblocks = (int)((m + 255) / 256);
     if (nblocks > kLossBlocks) nblocks = kLossBlocks;
     float* gcur = grads ? W.g[0] : nullptr;
-    if (!pdekan::launch_bs_residual(P.D, xs, stride_n, stride_d, W.act[nl], target ? target + p0 : nullptr, sigma,
-                                    rate, inv_n, res_out ? res_out + p0 : nullptr, gcur, W.loss_part, nblocks, m, st))
-      return fail(PDEKAN_ERR_ARG, "bs_step: %d input columns unsupported (2 or 6)", d);
-    if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
+    {
+      ProfScope ps_res(st, "bs_residual_loss", 0);
+      if (!pdekan::launch_bs_residual(P.D, xs, stride_n, stride_d, W.act[nl], target ? target + p0 : nullptr, sigma,
+                                      rate, inv_n, res_out ? res_out + p0 : nullptr, gcur, W.loss_part, nblocks, m, st))
+        return fail(PDEKAN_ERR_ARG, "bs_step: %d input columns unsupported (2 or 6)", d);
+      if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
+    }
     if (grads) {
       int cur = 0;
       for (int l = nl - 1; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
         rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], gnext, W.part, &grads[l],
-                          (accumulate || !first) ? 1 : 0, m, st);
+                          (accumulate || !first) ? 1 : 0, m, st, l);
         if (rc) return rc;
         cur ^= 1;
       }
@@ -301,6 +346,51 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     first = false;
   }
   return check_launch("bs_step");
+}
+
+int pdekan_profile_begin(void) {
+  for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof_recs.clear();
+  g_prof_sums.clear();
+  g_prof_on = true;
+  return PDEKAN_OK;
+}
+
+int pdekan_profile_end(void) {
+  g_prof_on = false;
+  int rc = PDEKAN_OK;
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+      rc = fail(PDEKAN_ERR_HIP, "profile: event timing failed for %s", r.name);
+    size_t k = 0;
+    for (; k < g_prof_sums.size(); ++k)
+      if (!strcmp(g_prof_sums[k].name, r.name)) break;
+    if (k == g_prof_sums.size()) {
+      ProfSum s;
+      strncpy(s.name, r.name, sizeof(s.name));
+      s.ms = 0.0; s.launches = 0;
+      g_prof_sums.push_back(s);
+    }
+    g_prof_sums[k].ms += ms;
+    g_prof_sums[k].launches += 1;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof_recs.clear();
+  return rc;
+}
+
+int pdekan_profile_count(void) { return (int)g_prof_sums.size(); }
+
+int pdekan_profile_entry(int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches) {
+  if (idx < 0 || idx >= (int)g_prof_sums.size() || !name || name_cap == 0)
+    return fail(PDEKAN_ERR_ARG, "profile_entry: bad index");
+  strncpy(name, g_prof_sums[idx].name, name_cap - 1);
+  name[name_cap - 1] = 0;
+  if (total_ms) *total_ms = g_prof_sums[idx].ms;
+  if (launches) *launches = g_prof_sums[idx].launches;
+  return PDEKAN_OK;
 }
 
 }  // extern "C"
