@@ -1,0 +1,198 @@
+// Fused head of the Black-Scholes PINN step for gfx950: last KAN layer (one
+// output) forward on jets + PDE residual + squared-error loss + the head's
+// backward (input-jet gradients and packed weight gradients) in ONE pass over
+// the head's input jets.  Replaces four launches and three re-reads of the
+// widest activation tensor.  Reference computation: KANLinear.forward
+// (efficient_kan/kan.py:153-166) of the last layer, residual_net / loss_res
+// (run1.py:120-149) and their autograd backward (run1.py:225).
+//
+// A wave owns one point at a time; its 64 lanes are the head's input features
+// (NF features per lane when in_features > 64).  Each lane evaluates its
+// feature's basis once, the output jet is a wavefront-level butterfly sum, every
+// lane then knows the residual and pulls the cotangent back through its own
+// feature.  Weight-gradient partial sums live in a per-wave LDS table whose row
+// i is touched by lane i only (plain read-modify-write, no atomics, so the
+// result is bitwise reproducible); tables are added in wave order at the end.
+#include <hip/hip_runtime.h>
+#include "kan_math.h"
+#include "kan_launch.h"
+
+namespace pdekan {
+
+template <int D, int D2, int NF>
+__global__ void __launch_bounds__(256)
+head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
+               const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ wp,
+               float sigma, float rate, float inv_n, float* __restrict__ res_out, float* __restrict__ ga,
+               float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G, int act) {
+  constexpr int J = 1 + D + D2;
+  static_assert(D2 == D - 1, "assets first, time last");
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  const int nw = blockDim.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_knots = reinterpret_cast<float*>(smem);        // [I][nk]
+  float* s_w = s_knots + I * nk;                          // [I][C1]
+  float* s_acc = s_w + I * C1;                            // [nw][I][C1]
+  float* s_loss = s_acc + nw * I * C1;                    // [nw]
+
+  for (int t = threadIdx.x; t < I * nk; t += blockDim.x) s_knots[t] = grid[t];
+  for (int t = threadIdx.x; t < I * C1; t += blockDim.x) s_w[t] = wp[t];
+  for (int t = threadIdx.x; t < nw * I * C1; t += blockDim.x) s_acc[t] = 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* acc = s_acc + wave * I * C1;
+  const float hs2 = 0.5f * sigma * sigma;
+  float loss_local = 0.0f;
+
+  for (int64_t p = (int64_t)blockIdx.x * nw + wave; p < N; p += (int64_t)gridDim.x * nw) {
+    float jet[NF][J];
+    Basis bs[NF];
+    Act av[NF];
+    float ph1[NF], ph2[NF], ph3[NF];
+    float y[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) y[j] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = lane + 64 * f;
+      const bool live = i < I;
+      const int ic = live ? i : 0;
+      const float* src = a + (p * I + ic) * J;
+#pragma unroll
+      for (int j = 0; j < J; ++j) jet[f][j] = src[j];
+      eval_basis<true>(s_knots + ic * nk, nk, jet[f][0], bs[f]);
+      av[f] = eval_act(act, jet[f][0]);
+      const float* w = s_w + ic * C1;
+      const float wb = live ? w[C] : 0.0f;
+      float p0 = wb * av[f].f0, p1 = wb * av[f].f1, p2 = wb * av[f].f2, p3 = wb * av[f].f3;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = bs[f].c0 + m;
+        const float wm = (live && c >= 0 && c < C) ? w[c] : 0.0f;
+        p0 += wm * bs[f].b[m]; p1 += wm * bs[f].d1[m]; p2 += wm * bs[f].d2[m]; p3 += wm * bs[f].d3[m];
+      }
+      ph1[f] = p1; ph2[f] = p2; ph3[f] = p3;
+      jet_accumulate<D, D2>(y, jet[f], p0, p1, p2);
+    }
+    // wavefront butterfly: every lane ends up with the full sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) y[j] += __shfl_xor(y[j], off);
+    }
+    float xs[D2];
+#pragma unroll
+    for (int d = 0; d < D2; ++d) xs[d] = x[p * stride_n + d * stride_d];
+    float res = y[D] + rate * y[0];
+#pragma unroll
+    for (int d = 0; d < D2; ++d) res = res - hs2 * xs[d] * xs[d] * y[1 + D + d] - rate * xs[d] * y[1 + d];
+    const float diff = res - (target ? target[p] : 0.0f);
+    if (lane == 0) {
+      loss_local += diff * diff;
+      if (res_out) res_out[p] = res;
+    }
+    if (part || ga) {
+      const float g = 2.0f * diff * inv_n;
+      float gy[J];
+      gy[0] = g * rate;
+#pragma unroll
+      for (int d = 0; d < D2; ++d) { gy[1 + d] = -g * rate * xs[d]; gy[1 + D + d] = -g * hs2 * xs[d] * xs[d]; }
+      gy[D] = g;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int i = lane + 64 * f;
+        if (i < I) {
+          float A0, A1, A2;
+          jet_pullback_coeffs<D, D2>(gy, jet[f], A0, A1, A2);
+          if (part) {
+            float* row = acc + i * C1;
+            row[C] += A0 * av[f].f0 + A1 * av[f].f1 + A2 * av[f].f2;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int c = bs[f].c0 + m;
+              if (c >= 0 && c < C) row[c] += A0 * bs[f].b[m] + A1 * bs[f].d1[m] + A2 * bs[f].d2[m];
+            }
+          }
+          if (ga) {
+            float* dst = ga + (p * I + i) * J;
+            dst[0] = A0 * ph1[f] + A1 * ph2[f] + A2 * ph3[f];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              float v = gy[1 + d] * ph1[f];
+              if (d < D2) v += 2.0f * jet[f][1 + d] * gy[1 + D + d] * ph2[f];
+              dst[1 + d] = v;
+            }
+#pragma unroll
+            for (int d = 0; d < D2; ++d) dst[1 + D + d] = gy[1 + D + d] * ph1[f];
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) s_loss[wave] = loss_local;
+  __syncthreads();
+  if (part) {
+    float* dst = part + (size_t)blockIdx.x * I * C1;
+    for (int t = threadIdx.x; t < I * C1; t += blockDim.x) {
+      float s = 0.0f;
+      for (int w = 0; w < nw; ++w) s += s_acc[w * I * C1 + t];
+      dst[t] = s;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int w = 0; w < nw; ++w) s += s_loss[w];
+    loss_part[blockIdx.x] = s;
+  }
+}
+
+static int head_waves(const LayerView& L) {
+  const size_t table = (size_t)L.I * L.C1() * 4;
+  if (table * 4 <= 48 * 1024) return 4;
+  if (table * 2 <= 64 * 1024) return 2;
+  return 1;
+}
+
+bool head_eligible(int D, const LayerView& L) {
+  return (D == 2 || D == 6) && L.O == 1 && L.I <= 256;
+}
+
+int head_blocks(int64_t N, const LayerView& L) {
+  const int nw = head_waves(L);
+  int64_t b = (N + (int64_t)nw * 16 - 1) / ((int64_t)nw * 16);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int D, int D2, int NF>
+static void head_launch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
+                        const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
+                        float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
+  const int nw = head_waves(L);
+  const size_t lds = ((size_t)L.I * L.nk() + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
+  auto k = head_bs_kernel<D, D2, NF>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, wp, sigma, rate, inv_n, res, ga, part, loss_part,
+                                   N, L.I, L.G, L.act);
+}
+
+template <int D, int D2>
+static void head_dispatch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
+                          const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
+                          float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
+  if (L.I <= 64) head_launch<D, D2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+  else if (L.I <= 128) head_launch<D, D2, 2>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+  else head_launch<D, D2, 4>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+}
+
+void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
+                    const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
+                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
+  if (D == 2) head_dispatch<2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+  else head_dispatch<6, 5>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+}
+
+}  // namespace pdekan

@@ -231,80 +231,78 @@ bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ 
 }
 
 // --------------------------------------------------------------------------
-// backward to the packed weights, any shape.  grid = (i-tiles, o-tiles,
-// point chunks); a block owns a TI x TO tile of edges and one chunk of points
-// and keeps a private column of C1 partial sums per edge in LDS (no atomics:
-// the result is bitwise reproducible).  Points are taken PT at a time: phase 1
-// evaluates the basis once per (point, input of the tile), phase 2 lets every
-// edge thread fold those points in.  Output: part[chunk][O][I][C1].
+// backward to the packed weights, any shape.  grid = (i-tiles, o-tiles, point
+// chunks).  A block owns a TI x TO tile of edges and one chunk of points; its
+// 256 threads are TE = TI*TO edges times PG point groups, and every thread
+// keeps a private column of C1 partial sums in LDS (no atomics, fixed order:
+// bitwise reproducible).  Points are taken PT at a time: phase 1 evaluates the
+// basis once per (point, input of the tile); in phase 2 thread (edge, group g)
+// folds in points g, g+PG, ...  The tile shape is chosen by the launcher so
+// skinny layers (2 inputs, or 1 output) still use every thread.
+// Output: part[chunk][O][I][C1].
 // --------------------------------------------------------------------------
-constexpr int kBwTI = 16, kBwTO = 16, kBwPT = 16;
+struct BwTile { int TI, TO, PG, PT; };
 
 template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
                           const float* __restrict__ grid, float* __restrict__ part,
-                          int64_t N, int I, int O, int G, int act, int64_t chunk_pts) {
+                          int64_t N, int I, int O, int G, int act, int64_t chunk_pts, BwTile T) {
   constexpr int J = 1 + D + D2;
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  const int TI = T.TI, TO = T.TO, PG = T.PG, PT = T.PT, TE = TI * TO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);                  // [kBwPT][kBwTI]
-  float* s_A = reinterpret_cast<float*>(recs + kBwPT * kBwTI);       // [kBwPT][kBwTI][3] jets folded
-  float* s_jet = s_A;                                                // alias name: input jets [PT][TI][J]
-  float* s_gy = s_jet + kBwPT * kBwTI * J;                           // [kBwPT][kBwTO][J]
-  float* s_knots = s_gy + kBwPT * kBwTO * J;                         // [kBwTI][nk]
-  float* s_acc = s_knots + kBwTI * nk;                               // [C][256]
+  EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);                  // [PT][TI]
+  float* s_jet = reinterpret_cast<float*>(recs + PT * TI);           // [PT][TI][J]
+  float* s_knots = s_jet + PT * TI * J;                              // [TI][nk]
+  float* s_acc = s_knots + TI * nk;                                  // [C1][256]
 
-  const int i0 = blockIdx.x * kBwTI, o0 = blockIdx.y * kBwTO;
-  const int ti = threadIdx.x % kBwTI, to = threadIdx.x / kBwTI;
+  const int i0 = blockIdx.x * TI, o0 = blockIdx.y * TO;
+  const int e = threadIdx.x % TE, pg = threadIdx.x / TE;
+  const int ti = e % TI, to = e / TI;
   const int i = i0 + ti, o = o0 + to;
   const bool edge_live = (i < I) && (o < O);
 
-  for (int t = threadIdx.x; t < kBwTI * nk; t += blockDim.x) {
+  for (int t = threadIdx.x; t < TI * nk; t += blockDim.x) {
     const int fi = i0 + t / nk;
     s_knots[t] = (fi < I) ? grid[fi * nk + t % nk] : 0.0f;
   }
-  for (int c = 0; c < C; ++c) s_acc[c * 256 + threadIdx.x] = 0.0f;
-  float acc_base = 0.0f;
+  for (int c = 0; c < C1; ++c) s_acc[c * 256 + threadIdx.x] = 0.0f;
   __syncthreads();
 
   const int64_t pbeg = (int64_t)blockIdx.z * chunk_pts;
   const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
-  for (int64_t pb = pbeg; pb < pend; pb += kBwPT) {
-    const int npts = (int)((pend - pb < kBwPT) ? (pend - pb) : kBwPT);
-    // phase 1: thread (pp, ti) evaluates input i0+ti at point pb+pp
-    {
-      const int pp = threadIdx.x / kBwTI;        // 256 / 16 = 16 = kBwPT
-      const int fi = i0 + ti;
-      if (pp < npts && fi < I) {
+  for (int64_t pb = pbeg; pb < pend; pb += PT) {
+    const int npts = (int)((pend - pb < PT) ? (pend - pb) : PT);
+    for (int pair = threadIdx.x; pair < npts * TI; pair += blockDim.x) {
+      const int pp = pair / TI, t1 = pair - pp * TI;
+      const int fi = i0 + t1;
+      if (fi < I) {
         const float* src = a + ((pb + pp) * I + fi) * J;
         float jet[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[(pp * kBwTI + ti) * J + j] = jet[j]; }
+        for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
         Basis bs;
-        eval_basis<false>(s_knots + ti * nk, nk, jet[0], bs);
+        eval_basis<false>(s_knots + t1 * nk, nk, jet[0], bs);
         const Act av = eval_act(act, jet[0]);
         EdgeRec r;
 #pragma unroll
         for (int m = 0; m < 4; ++m) { r.b[m] = bs.b[m]; r.d1[m] = bs.d1[m]; r.d2[m] = bs.d2[m]; }
         r.f0 = av.f0; r.f1 = av.f1; r.f2 = av.f2; r.c0 = bs.c0;
-        recs[pp * kBwTI + ti] = r;
-      }
-      // and stage the cotangents of the tile's outputs
-      const int go = o0 + ti;                      // reuse (pp, ti) as (point, output)
-      if (pp < npts && go < O) {
-        const float* src = gy + ((pb + pp) * O + go) * J;
-#pragma unroll
-        for (int j = 0; j < J; ++j) s_gy[(pp * kBwTO + ti) * J + j] = src[j];
+        recs[pair] = r;
       }
     }
     __syncthreads();
     if (edge_live) {
-      for (int pp = 0; pp < npts; ++pp) {
-        const EdgeRec r = recs[pp * kBwTI + ti];
+      for (int pp = pg; pp < npts; pp += PG) {
+        const EdgeRec r = recs[pp * TI + ti];
+        float g[J];
+        const float* gsrc = gy + ((pb + pp) * O + o) * J;
+#pragma unroll
+        for (int j = 0; j < J; ++j) g[j] = gsrc[j];
         float A0, A1, A2;
-        jet_pullback_coeffs<D, D2>(s_gy + (pp * kBwTO + to) * J, s_jet + (pp * kBwTI + ti) * J, A0, A1, A2);
-        acc_base += A0 * r.f0 + A1 * r.f1 + A2 * r.f2;
+        jet_pullback_coeffs<D, D2>(g, s_jet + (pp * TI + ti) * J, A0, A1, A2);
+        s_acc[C * 256 + threadIdx.x] += A0 * r.f0 + A1 * r.f1 + A2 * r.f2;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int c = r.c0 + m;
@@ -314,11 +312,32 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
     }
     __syncthreads();
   }
-  if (edge_live) {
+  if (edge_live && pg == 0) {
     float* dst = part + (((size_t)blockIdx.z * O + o) * I + i) * C1;
-    for (int c = 0; c < C; ++c) dst[c] = s_acc[c * 256 + threadIdx.x];
-    dst[C] = acc_base;
+    for (int c = 0; c < C1; ++c) {
+      float sum = 0.0f;
+      for (int g = 0; g < PG; ++g) sum += s_acc[c * 256 + e + TE * g];
+      dst[c] = sum;
+    }
   }
+}
+
+// --------------------------------------------------------------------------
+// sum part[chunk][total] over the chunks into out[total]: a block takes 64
+// consecutive elements, its 4 waves take every 4th chunk each (coalesced 256-byte
+// reads), and the 4 partial sums are added in a fixed order.
+// --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, float* __restrict__ out) {
+  __shared__ float s_r[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + lane;
+  float s = 0.0f;
+  if (e < total)
+    for (int k = g; k < nchunks; k += 4) s += part[(size_t)k * total + e];
+  s_r[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && e < total) out[e] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
 }
 
 // --------------------------------------------------------------------------
@@ -465,11 +484,24 @@ static void bwd_input_t(const LayerView& L, const float* a, const float* gy, con
   bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, wp, ga, N, L.I, L.O, L.G, L.act);
 }
 
+static inline int pow2_ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
+
+static BwTile bw_tile(int I, int O) {
+  BwTile T;
+  T.TI = pow2_ceil(I); if (T.TI > 16) T.TI = 16;
+  T.TO = pow2_ceil(O); if (T.TO > 256 / T.TI) T.TO = 256 / T.TI;
+  T.PG = 256 / (T.TI * T.TO);
+  T.PT = 256 / T.TI; if (T.PT > 128) T.PT = 128;
+  if (T.PT < T.PG) T.PT = T.PG;
+  return T;
+}
+
 int generic_weight_chunks(int64_t N, int I, int O) {
   // enough blocks to fill the chip, few enough that the partials stay small
-  const int tiles = ((I + kBwTI - 1) / kBwTI) * ((O + kBwTO - 1) / kBwTO);
+  const BwTile T = bw_tile(I, O);
+  const int tiles = ((I + T.TI - 1) / T.TI) * ((O + T.TO - 1) / T.TO);
   int64_t want = (2048 + tiles - 1) / tiles;
-  const int64_t max_by_pts = (N + 255) / 256;
+  const int64_t max_by_pts = (N + 511) / 512;
   if (want > max_by_pts) want = max_by_pts;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
@@ -480,12 +512,13 @@ template <int D, int D2>
 static void bwd_weight_t(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
                          int64_t N, hipStream_t st) {
   constexpr int J = 1 + D + D2;
+  const BwTile T = bw_tile(L.I, L.O);
   int64_t chunk = (N + nchunks - 1) / nchunks;
-  chunk = (chunk + kBwPT - 1) / kBwPT * kBwPT;
-  dim3 g((L.I + kBwTI - 1) / kBwTI, (L.O + kBwTO - 1) / kBwTO, nchunks);
-  const size_t lds = sizeof(EdgeRec) * kBwPT * kBwTI + (size_t)kBwPT * kBwTI * J * 4 +
-                     (size_t)kBwPT * kBwTO * J * 4 + (size_t)kBwTI * L.nk() * 4 + (size_t)L.C() * 256 * 4;
-  bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, part, N, L.I, L.O, L.G, L.act, chunk);
+  chunk = (chunk + T.PT - 1) / T.PT * T.PT;
+  dim3 g((L.I + T.TI - 1) / T.TI, (L.O + T.TO - 1) / T.TO, nchunks);
+  const size_t lds = sizeof(EdgeRec) * T.PT * T.TI + (size_t)T.PT * T.TI * J * 4 + (size_t)T.TI * L.nk() * 4 +
+                     (size_t)L.C1() * 256 * 4;
+  bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, part, N, L.I, L.O, L.G, L.act, chunk, T);
 }
 
 template <int D, int D2>
@@ -534,11 +567,17 @@ bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a
   return true;
 }
 
-void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* g_base, float* g_spline,
-                          float* g_scaler, int accumulate, hipStream_t st) {
+void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st) {
   const int edges = L.O * L.I;
+  const float* src = part;
+  if (nchunks > 1) {
+    const size_t total = L.packed_floats();
+    sum_partials_kernel<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(part, nchunks, total, sum_buf);
+    src = sum_buf;
+  }
   const int blocks = (edges + 127) / 128;
-  reduce_unpack_kernel<<<blocks, 128, 0, st>>>(part, nchunks, L.spline_w, L.scaler, g_base, g_spline, g_scaler,
+  reduce_unpack_kernel<<<blocks, 128, 0, st>>>(src, 1, L.spline_w, L.scaler, g_base, g_spline, g_scaler,
                                                L.I, L.O, L.C(), accumulate);
 }
 

@@ -30,13 +30,21 @@ bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a,
 int generic_weight_chunks(int64_t N, int I, int O);
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
                                int nchunks, int64_t N, hipStream_t st);
-void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* g_base, float* g_spline,
-                          float* g_scaler, int accumulate, hipStream_t st);
+// sum_buf: packed_floats() floats of scratch, used when nchunks > 1
+void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st);
 bool launch_bs_residual(int D, const float* x, int64_t stride_n, int64_t stride_d, const float* vjet,
                         const float* target, float sigma, float rate, float inv_n, float* res, float* gy,
                         float* loss_part, int nblocks, int64_t N, hipStream_t st);
 void launch_loss_finish(const float* loss_part, int nparts, float inv_n, float* loss_out, int accumulate,
                         hipStream_t st);
+
+// kan_head.hip: last layer (one output) + residual + loss + its backward, fused
+bool head_eligible(int D, const LayerView& L);
+int head_blocks(int64_t N, const LayerView& L);
+void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t stride_n, int64_t stride_d,
+                    const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
+                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st);
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);

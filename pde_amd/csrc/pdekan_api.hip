@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -48,6 +49,11 @@ struct ProfScope {
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof_recs[idx].b, st); }
 };
 
+bool getenv_flag(const char* name) {
+  const char* v = getenv(name);
+  return v && v[0] == '1';
+}
+
 bool jet_supported(int d, int d2) { return (d == 0 && d2 == 0) || (d == 2 && d2 == 1) || (d == 6 && d2 == 5); }
 
 int to_view(const PdekanLayer* l, pdekan::LayerView& v) {
@@ -85,7 +91,7 @@ int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
 
 size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   const size_t packed = align_up(L.packed_floats() * 4) / 4;
-  return 2 * packed + align_up((size_t)weight_chunks(D, D2, L, n) * L.packed_floats() * 4) / 4;
+  return 2 * packed + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4;
 }
 
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, float* y, int64_t n,
@@ -118,7 +124,7 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
         return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
     }
     ProfScope ps(st, "L%d.reduce_unpack", li);
-    pdekan::launch_reduce_unpack(L, part, nch, g->base_weight, g->spline_weight,
+    pdekan::launch_reduce_unpack(L, part, nch, part + (size_t)nch * L.packed_floats(), g->base_weight, g->spline_weight,
                                  L.scaler ? g->spline_scaler : nullptr, accumulate, st);
   }
   if (ga) {
@@ -156,8 +162,15 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
     if (l > 0 && P.L[l].I != P.L[l - 1].O) return fail(PDEKAN_ERR_ARG, "layer %d input width mismatch", l);
     if (P.L[l].I > P.maxw) P.maxw = P.L[l].I;
     if (P.L[l].O > P.maxw) P.maxw = P.L[l].O;
-    const size_t pf = (size_t)weight_chunks(D, D2, P.L[l], P.mb) * P.L[l].packed_floats();
+    const size_t pf = (size_t)(weight_chunks(D, D2, P.L[l], P.mb) + 1) * P.L[l].packed_floats();
     if (pf > P.part_floats) P.part_floats = pf;
+  }
+  {
+    const pdekan::LayerView& H = P.L.back();
+    if (pdekan::head_eligible(D, H)) {
+      const size_t pf = (size_t)(pdekan::head_blocks(P.mb, H) + 1) * H.packed_floats();
+      if (pf > P.part_floats) P.part_floats = pf;
+    }
   }
   return PDEKAN_OK;
 }
@@ -245,7 +258,7 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   Carver c(ws, ws_bytes);
   float* wp = c.take(L.packed_floats());
   float* wt = c.take(L.packed_floats());
-  float* part = c.take((size_t)weight_chunks(n_dir, n_second, L, n) * L.packed_floats());
+  float* part = c.take((size_t)(weight_chunks(n_dir, n_second, L, n) + 1) * L.packed_floats());
   if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   pdekan::launch_pack_weights(L, wp, wt, st);
@@ -319,26 +332,49 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       ProfScope ps(st, "seed_jets", 0);
       pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
     }
-    for (int l = 0; l < nl; ++l) {
+    const pdekan::LayerView& H = P.L[nl - 1];
+    const bool fused_head = pdekan::head_eligible(P.D, H) && !getenv_flag("PDEKAN_DISABLE_FUSED_HEAD");
+    const int n_fwd = fused_head ? nl - 1 : nl;
+    for (int l = 0; l < n_fwd; ++l) {
       rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.act[l + 1], m, st, l);
       if (rc) return rc;
     }
-    int nblocks = (int)((m + 255) / 256);
-    if (nblocks > kLossBlocks) nblocks = kLossBlocks;
-    float* gcur = grads ? W.g[0] : nullptr;
-    {
+    const float* tgt = target ? target + p0 : nullptr;
+    float* res = res_out ? res_out + p0 : nullptr;
+    const int acc_flag = (accumulate || !first) ? 1 : 0;
+    int top = nl - 1;            // first layer the generic backward loop still has to do
+    int cur = 0;
+    if (fused_head) {
+      const int nblocks = pdekan::head_blocks(m, H);
+      {
+        ProfScope ps(st, "L%d.head_fused", nl - 1);
+        pdekan::launch_head_bs(P.D, H, W.act[nl - 1], xs, stride_n, stride_d, tgt, W.wp[nl - 1], sigma, rate, inv_n,
+                               res, (grads && nl > 1) ? W.g[0] : nullptr, grads ? W.part : nullptr, W.loss_part,
+                               nblocks, m, st);
+        if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
+      }
+      if (grads) {
+        const PdekanLayerGrad& g = grads[nl - 1];
+        if (!g.base_weight || !g.spline_weight || (H.scaler && !g.spline_scaler))
+          return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
+        ProfScope ps(st, "L%d.reduce_unpack", nl - 1);
+        pdekan::launch_reduce_unpack(H, W.part, nblocks, W.part + (size_t)nblocks * H.packed_floats(), g.base_weight,
+                                     g.spline_weight, H.scaler ? g.spline_scaler : nullptr, acc_flag, st);
+      }
+      top = nl - 2;
+    } else {
+      int nblocks = (int)((m + 255) / 256);
+      if (nblocks > kLossBlocks) nblocks = kLossBlocks;
       ProfScope ps_res(st, "bs_residual_loss", 0);
-      if (!pdekan::launch_bs_residual(P.D, xs, stride_n, stride_d, W.act[nl], target ? target + p0 : nullptr, sigma,
-                                      rate, inv_n, res_out ? res_out + p0 : nullptr, gcur, W.loss_part, nblocks, m, st))
+      if (!pdekan::launch_bs_residual(P.D, xs, stride_n, stride_d, W.act[nl], tgt, sigma, rate, inv_n, res,
+                                      grads ? W.g[0] : nullptr, W.loss_part, nblocks, m, st))
         return fail(PDEKAN_ERR_ARG, "bs_step: %d input columns unsupported (2 or 6)", d);
       if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
     }
     if (grads) {
-      int cur = 0;
-      for (int l = nl - 1; l >= 0; --l) {
+      for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
-        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], gnext, W.part, &grads[l],
-                          (accumulate || !first) ? 1 : 0, m, st, l);
+        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], gnext, W.part, &grads[l], acc_flag, m, st, l);
         if (rc) return rc;
         cur ^= 1;
       }

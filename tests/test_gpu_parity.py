@@ -226,3 +226,42 @@ def test_mfma_and_streaming_paths_agree(monkeypatch):
     monkeypatch.delenv("PDEKAN_DISABLE_MFMA")
     assert abs(l_mfma - l_gen) <= 2e-6 * abs(l_gen)
     assert max_rel(g_mfma.cpu(), g_gen.cpu()) <= 5e-6
+
+
+@pytest.mark.parametrize("case", ["cfg1_silu", "cfg2_silu", "cfg5_narrow"])
+def test_fused_head_and_separate_kernels_agree(golden, case, monkeypatch):
+    """The fused last-layer + residual + loss + backward kernel against the
+    same step done with the separate layer kernels."""
+    from pde_amd.pinn import BlackScholesStep
+    rec = golden(case)
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"]).cuda()
+    fused = BlackScholesStep(m)
+    r0 = torch.empty(x.size(0), device="cuda")
+    l0 = fused(x, residual_out=r0).item()
+    g0 = fused.flat_grad.clone()
+    monkeypatch.setenv("PDEKAN_DISABLE_FUSED_HEAD", "1")
+    sep = BlackScholesStep(m)
+    r1 = torch.empty(x.size(0), device="cuda")
+    l1 = sep(x, residual_out=r1).item()
+    monkeypatch.delenv("PDEKAN_DISABLE_FUSED_HEAD")
+    assert abs(l0 - l1) <= 2e-6 * abs(l1)
+    assert max_rel(r0.cpu(), r1.cpu()) <= 2e-6
+    assert max_rel(g0.cpu(), sep.flat_grad.cpu()) <= 5e-6
+    check(sep.flat_grad[: m.layers[0].base_weight.numel()].view_as(m.layers[0].base_weight), rec,
+          "grad.layers.0.base_weight")
+
+
+def test_single_layer_model_step():
+    """KAN [2,1]: the head is the whole model."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model([2, 1], 5, 21)
+    layers = O.layers_from_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    x = torch.rand(300, 2, generator=torch.Generator().manual_seed(2))
+    ref = O.pinn_step(x.double(), O.layers_from_state_dict(m.state_dict(), dtype=torch.float64), "silu")
+    m = m.cuda()
+    step = BlackScholesStep(m)
+    loss = step(x.cuda()).item()
+    flat = torch.cat([ref["grads"][0][k].flatten() for k in ("base_weight", "spline_weight", "spline_scaler")])
+    assert abs(loss - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    assert max_rel(step.flat_grad.cpu(), flat) <= TOL
