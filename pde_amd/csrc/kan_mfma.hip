@@ -63,9 +63,32 @@ __device__ __forceinline__ void write_expanded(float* tile, int RS, int f_local,
   }
 }
 
+// register <-> memory helpers (plain functions: arrays captured by a lambda end up in scratch)
+template <int WV, int LIMIT>
+__device__ __forceinline__ void fetch_rows16(f32x4 (&wreg)[WV], const float* src, int row_stride, int tid) {
+  // LIMIT float4 in rows of 16 float4 (64 floats): idx -> row idx>>4, column 4*(idx&15)
+#pragma unroll
+  for (int v = 0; v < WV; ++v) {
+    int idx = tid + v * 256;
+    if (idx > LIMIT - 1) idx = LIMIT - 1;                // clamp: the load is unconditional, the store is not
+    wreg[v] = *reinterpret_cast<const f32x4*>(src + (size_t)(idx >> 4) * row_stride + (idx & 15) * 4);
+  }
+}
+template <int WV, int LIMIT>
+__device__ __forceinline__ void store_rows16(const f32x4 (&wreg)[WV], float* dst, int tid) {
+#pragma unroll
+  for (int v = 0; v < WV; ++v) {
+    const int idx = tid + v * 256;
+    if (idx < LIMIT) *reinterpret_cast<f32x4*>(dst + (idx >> 4) * 64 + (idx & 15) * 4) = wreg[v];
+  }
+}
+
 // ==========================================================================
 // forward:  block = 4 waves, 64 points x 64 outputs; wave = 16 points (64 rows)
-// K is walked in slabs of KI features (KK = KI*C1 columns, even).
+// K is walked in slabs of KI features (KK = KI*C1 columns, even).  The next
+// slab's weights, knots and input jets are fetched into registers before the
+// MFMA loop of the current slab, so their latency hides behind the matrix work;
+// two barriers per slab.
 // ==========================================================================
 template <int C1, int KI>
 __global__ void __launch_bounds__(256, 2)
@@ -74,10 +97,12 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
   constexpr int KK = KI * C1;
   static_assert(KK % 2 == 0, "k-step of 2");
   constexpr int nk = C1 + 3;               // G + 7
+  constexpr int WV = (KK * 16 + 255) / 256;
+  static_assert(KI * nk <= 256, "one knot per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sW = reinterpret_cast<float*>(smem);            // [KK][64]
   float* sA = sW + KK * 64;                              // [4][KK][64]
-  float* sK = sA + 4 * KK * 64;                          // [KI][kKnotPad]
+  float* sK = sA + 4 * KK * 64;                          // [2][KI][kKnotPad]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p_local = lane & 15, f_local = lane >> 4;
@@ -85,29 +110,40 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
   const int o0 = blockIdx.y * 64;
   float* tileA = sA + wave * KK * 64;
   const int h = lane >> 5, r = lane & 31;
+  int64_t pj = P0 + p_local;
+  if (pj > N - 1) pj = N - 1;
+  const int kf = tid / nk, kk_ = tid - kf * nk;          // knot slot of this thread
+
+  f32x4 wreg[WV];                                        // native vectors: HIP float4 copies pin arrays in scratch
+  float kreg = 0.f;
+  float4 jet = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* wsrc = wt + o0;                           // slab i0 starts at row i0*C1
+  const bool knot_thread = tid < KI * nk;
+  const bool gen_lane = f_local < KI;
+
+  if (knot_thread) sK[kf * kKnotPad + kk_] = grid[(size_t)kf * nk + kk_];
+  fetch_rows16<WV, KK * 16>(wreg, wsrc, O, tid);
+  if (gen_lane) jet = a[pj * I + f_local];
+  if (KI < I && knot_thread) kreg = grid[(size_t)(KI + kf) * nk + kk_];
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
-  for (int i0 = 0; i0 < I; i0 += KI) {
-    __syncthreads();                                     // previous slab fully consumed
-    for (int idx = tid; idx < KK * 16; idx += 256) {
-      const int kk = idx >> 4, c4 = idx & 15;
-      const float4 v = *reinterpret_cast<const float4*>(wt + (size_t)(i0 * C1 + kk) * O + o0 + c4 * 4);
-      *reinterpret_cast<float4*>(sW + kk * 64 + c4 * 4) = v;
-    }
-    for (int idx = tid; idx < KI * nk; idx += 256) {
-      const int f = idx / nk, k = idx - f * nk;
-      sK[f * kKnotPad + k] = grid[(size_t)(i0 + f) * nk + k];
-    }
-    __syncthreads();
-    if (f_local < KI) {
-      int64_t p = P0 + p_local;
-      if (p > N - 1) p = N - 1;
-      const float4 jet = a[p * I + i0 + f_local];
+  int s = 0;
+  for (int i0 = 0; i0 < I; i0 += KI, ++s) {
+    __syncthreads();                                     // previous slab consumed; knots of this slab visible
+    store_rows16<WV, KK * 16>(wreg, sW, tid);
+    const bool more = i0 + KI < I;
+    if (more && knot_thread) sK[((s + 1) & 1) * KI * kKnotPad + kf * kKnotPad + kk_] = kreg;
+    if (gen_lane) {
       float4 e[5];
       int c0;
-      expand_jets(sK + f_local * kKnotPad, nk, act, jet, e, c0);
+      expand_jets(sK + (s & 1) * KI * kKnotPad + f_local * kKnotPad, nk, act, jet, e, c0);
       write_expanded<C1>(tileA, 64, f_local, p_local, e, c0);
+    }
+    if (more) {
+      fetch_rows16<WV, KK * 16>(wreg, wsrc + (size_t)(i0 + KI) * C1 * O, O, tid);
+      if (gen_lane) jet = a[pj * I + i0 + KI + f_local];
+      if (i0 + 2 * KI < I && knot_thread) kreg = grid[(size_t)(i0 + 2 * KI + kf) * nk + kk_];
     }
     __syncthreads();
 #pragma unroll 4
@@ -140,22 +176,24 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
 // weight gradients: block = 4 waves; wave w owns KIW features (cols = KIW*C1,
 // a multiple of 16) x 64 outputs of accumulators and the block walks its chunk
 // of points PB at a time.  D[i = column][j = output] += E[row][column] * gY[row][output],
-// one 16x16x4 MFMA reduces over the 4 jets of one point.
+// one 16x16x4 MFMA reduces over the 4 jets of one point.  The gY tile and input
+// jets of the next pass are fetched into registers before the MFMA loop.
 // Output: part[chunk][O][I][C1] (summed over chunks by reduce_unpack).
 // ==========================================================================
-template <int C1, int KIW>
+template <int C1, int KIW, int PB>
 __global__ void __launch_bounds__(256, 2)
 bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
                        const float* __restrict__ grid, float* __restrict__ part,
                        int64_t N, int I, int O, int act, int64_t chunk_pts) {
   constexpr int COLS = KIW * C1;
   static_assert(COLS % 16 == 0, "16-wide column tiles");
+  static_assert(PB * KIW <= 64, "one (point, feature) per lane");
   constexpr int NT = COLS / 16;
-  constexpr int PB = 64 / KIW;             // points per pass: one (point, feature) per lane
   constexpr int ROWS = PB * 4;
   constexpr int RS = ROWS + 4;             // E tile row stride (16-byte aligned, not a multiple of 32)
   constexpr int RG = 80;                   // gY tile row stride: quarter-waves land on disjoint banks
   constexpr int nk = C1 + 3;
+  constexpr int GV = (PB * 64 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sE = reinterpret_cast<float*>(smem);            // [4][COLS][RS]
   float* sG = sE + 4 * COLS * RS;                        // [ROWS][RG]
@@ -163,6 +201,7 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p_local = lane % PB, f_local = lane / PB;
+  const bool gen_lane = f_local < KIW;
   const int i0 = (blockIdx.x * 4 + wave) * KIW;
   const int o0 = blockIdx.y * 64;
   float* tileE = sE + wave * COLS * RS;
@@ -180,24 +219,43 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 
   const int64_t pbeg = (int64_t)blockIdx.z * chunk_pts;
   const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+
+  float4 greg[GV];
+  float4 jet = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PDEKAN_BWW_FETCH(PBASE)                                                          \
+  {                                                                                      \
+    _Pragma("unroll") for (int v = 0; v < GV; ++v) {                                     \
+      const int idx = tid + v * 256;                                                     \
+      const int p = idx >> 6, o = idx & 63;                                              \
+      greg[v] = make_float4(0.f, 0.f, 0.f, 0.f);                                         \
+      if (idx < PB * 64 && (PBASE) + p < pend) greg[v] = gy[((PBASE) + p) * O + o0 + o]; \
+    }                                                                                    \
+    if (gen_lane) {                                                                      \
+      int64_t pc = (PBASE) + p_local;                                                    \
+      if (pc > N - 1) pc = N - 1;                                                        \
+      jet = a[pc * I + i0 + f_local];                                                    \
+    }                                                                                    \
+  }
+  if (pbeg < pend) PDEKAN_BWW_FETCH(pbeg)
+
   for (int64_t pb = pbeg; pb < pend; pb += PB) {
     __syncthreads();                                     // previous pass consumed (and knots visible)
-    for (int idx = tid; idx < PB * 64; idx += 256) {
-      const int p = idx >> 6, o = idx & 63;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pb + p < pend) v = gy[(pb + p) * O + o0 + o];
-      float* dst = sG + (p * 4) * RG + o;
-      dst[0] = v.x; dst[RG] = v.y; dst[2 * RG] = v.z; dst[3 * RG] = v.w;
+#pragma unroll
+    for (int v = 0; v < GV; ++v) {
+      const int idx = tid + v * 256;
+      if (idx < PB * 64) {
+        const int p = idx >> 6, o = idx & 63;
+        float* dst = sG + (p * 4) * RG + o;
+        dst[0] = greg[v].x; dst[RG] = greg[v].y; dst[2 * RG] = greg[v].z; dst[3 * RG] = greg[v].w;
+      }
     }
-    {
-      int64_t p = pb + p_local;
-      if (p > N - 1) p = N - 1;
-      const float4 jet = a[p * I + i0 + f_local];
+    if (gen_lane) {
       float4 e[5];
       int c0;
       expand_jets(sK + (wave * KIW + f_local) * kKnotPad, nk, act, jet, e, c0);
       write_expanded<C1>(tileE, RS, f_local, p_local, e, c0);
     }
+    if (pb + PB < pend) PDEKAN_BWW_FETCH(pb + PB)
     __syncthreads();
 #pragma unroll 2
     for (int t = 0; t < PB; ++t) {
@@ -212,14 +270,14 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
       }
     }
   }
+#undef PDEKAN_BWW_FETCH
   // D[i = column][j = output]: this lane holds columns n*16 + 4q + reg of output m*16 + l15
-  const int C1r = C1;
-  float* dst0 = part + ((size_t)blockIdx.z * O + o0) * I * C1r + (size_t)i0 * C1r;
+  float* dst0 = part + ((size_t)blockIdx.z * O + o0) * I * C1 + (size_t)i0 * C1;
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      float* dst = dst0 + (size_t)(m * 16 + l15) * I * C1r + n * 16 + 4 * q;
+      float* dst = dst0 + (size_t)(m * 16 + l15) * I * C1 + n * 16 + 4 * q;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) dst[rg] = acc[n][m][rg];
     }
@@ -230,9 +288,11 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 //   gE[row][column] = sum_o gY[row][o] * W[o][column]       (16x16x4 MFMA, A = gY kept in registers)
 // then each (point, feature) lane pulls its 4+1 live columns out of LDS and
 // applies the chain rule through B', B'', B''' and the activation derivatives.
+// The W tile of the next step and the jets the epilogue needs are fetched into
+// registers ahead of the MFMA loop.
 // ==========================================================================
 template <int C1, int KIS, int OT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (OT > 1 ? 1 : 2))   // wide layers keep 32*OT gY registers per lane
 bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
                       const float* __restrict__ grid, const float* __restrict__ wp,
                       float4* __restrict__ ga, int64_t N, int I, int O, int act) {
@@ -248,33 +308,60 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
   constexpr int T_FLOATS = 128 * RT;
   constexpr int U_FLOATS = (S_FLOATS > W_FLOATS ? (S_FLOATS > T_FLOATS ? S_FLOATS : T_FLOATS)
                                                 : (W_FLOATS > T_FLOATS ? W_FLOATS : T_FLOATS));
+  constexpr int WV = (64 * (COLS / 4) + 255) / 256;       // float4 of W tile per thread
+  constexpr int NP = (8 * KIS + 63) / 64;                 // (point, feature) pairs per lane
+  static_assert(KIS * nk <= 2 * 256, "knots: at most two per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sU = reinterpret_cast<float*>(smem);             // union: gY staging / W slab / gE tiles
+  float* sU = reinterpret_cast<float*>(smem);             // union: gY staging / W tile / gE tiles
   float* sK = sU + U_FLOATS;                              // [KIS][kKnotPad]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, l15 = lane & 15;
-  const int64_t PB0 = (int64_t)blockIdx.x * 32;           // block's first point
-  const int64_t PW0 = PB0 + wave * 8;                     // wave's first point
+  const int64_t PB0 = (int64_t)blockIdx.x * 32;           // first point of the block
+  const int64_t PW0 = PB0 + wave * 8;                     // first point of the wave
 
-  // ---- gY of this wave's 32 rows into registers, 64 outputs at a time ----
+  // ---- gY of the 32 rows of this wave into registers, 64 outputs at a time ----
+  // (macros with literal chunk numbers: every register array below must be
+  //  indexed by compile-time constants or it is demoted to scratch memory)
   float afrag[OT][2][16];
-#pragma unroll
-  for (int oc = 0; oc < OT; ++oc) {
-    __syncthreads();
-    for (int idx = tid; idx < 32 * 64; idx += 256) {
-      const int p = idx >> 6, o = idx & 63;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PB0 + p < N) v = gy[(PB0 + p) * O + oc * 64 + o];
-      float* dst = sU + (p * 4) * RT + o;
-      dst[0] = v.x; dst[RT] = v.y; dst[2 * RT] = v.z; dst[3 * RT] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) afrag[oc][mt][t] = sU[(wave * 32 + mt * 16 + l15) * RT + 4 * t + q];
+#define PDEKAN_STAGE_GY(OC)                                                                        \
+  {                                                                                                \
+    __syncthreads();                                                                               \
+    for (int idx = tid; idx < 32 * 64; idx += 256) {                                               \
+      const int p = idx >> 6, o = idx & 63;                                                        \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+      if (PB0 + p < N) v = gy[(PB0 + p) * O + (OC) * 64 + o];                                      \
+      float* dst = sU + (p * 4) * RT + o;                                                          \
+      dst[0] = v.x; dst[RT] = v.y; dst[2 * RT] = v.z; dst[3 * RT] = v.w;                           \
+    }                                                                                              \
+    __syncthreads();                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                               \
+      _Pragma("unroll") for (int t = 0; t < 16; ++t)                                               \
+        afrag[OC][mt][t] = sU[(wave * 32 + mt * 16 + l15) * RT + 4 * t + q];                       \
   }
+  PDEKAN_STAGE_GY(0)
+  if constexpr (OT > 1) PDEKAN_STAGE_GY(1)
+  if constexpr (OT > 2) { PDEKAN_STAGE_GY(2) PDEKAN_STAGE_GY(3) }
+#undef PDEKAN_STAGE_GY
+
+  f32x4 wreg[WV];                                         // native vectors: HIP float4 copies pin arrays in scratch
+  float kreg0 = 0.f, kreg1 = 0.f;
+  f32x4 jete[NP];
+  const int k0f = tid / nk, k0k = tid % nk, k1f = (tid + 256) / nk, k1k = (tid + 256) % nk;
+#define PDEKAN_FETCH_W(I0, OC)                                                                     \
+  _Pragma("unroll") for (int v = 0; v < WV; ++v) {                                                 \
+    int idx = tid + v * 256;                                                                       \
+    if (idx > 64 * (COLS / 4) - 1) idx = 64 * (COLS / 4) - 1;                                      \
+    const int o = idx / (COLS / 4), c4 = idx - o * (COLS / 4);                                     \
+    wreg[v] = *reinterpret_cast<const f32x4*>(wp + ((size_t)((OC) * 64 + o) * I + (I0)) * C1 + c4 * 4); \
+  }
+#define PDEKAN_FETCH_KNOTS(I0)                                                                     \
+  {                                                                                                \
+    if (tid < KIS * nk) kreg0 = grid[(size_t)((I0) + k0f) * nk + k0k];                             \
+    if (tid + 256 < KIS * nk) kreg1 = grid[(size_t)((I0) + k1f) * nk + k1k];                       \
+  }
+  PDEKAN_FETCH_W(0, 0)
+  PDEKAN_FETCH_KNOTS(0)
 
   for (int i0 = 0; i0 < I; i0 += KIS) {
     f32x4 acc[2][NT];
@@ -282,31 +369,50 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[mt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int oc = 0; oc < OT; ++oc) {
-      __syncthreads();                                    // union region free again
-      for (int idx = tid; idx < 64 * (COLS / 4); idx += 256) {
-        const int o = idx / (COLS / 4), c4 = idx - o * (COLS / 4);
-        const float4 v = *reinterpret_cast<const float4*>(wp + ((size_t)(oc * 64 + o) * I + i0) * C1 + c4 * 4);
-        *reinterpret_cast<float4*>(sU + o * RW + c4 * 4) = v;
-      }
-      if (oc == 0)
-        for (int idx = tid; idx < KIS * nk; idx += 256) {
-          const int f = idx / nk, k = idx - f * nk;
-          sK[f * kKnotPad + k] = grid[(size_t)(i0 + f) * nk + k];
-        }
-      __syncthreads();
-#pragma unroll 4
-      for (int t = 0; t < 16; ++t) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float bv = sU[(4 * t + q) * RW + n * 16 + l15];
-          acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[oc][0][t], bv, acc[0][n], 0, 0, 0);
-          acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[oc][1][t], bv, acc[1][n], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();                                      // every wave is done with the W slab
+#define PDEKAN_CHUNK(OC)                                                                           \
+  {                                                                                                \
+    __syncthreads(); /* union region free again */                                                 \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) {                                               \
+      const int idx = tid + v * 256;                                                               \
+      if (idx < 64 * (COLS / 4)) {                                                                 \
+        const int o = idx / (COLS / 4), c4 = idx - o * (COLS / 4);                                 \
+        *reinterpret_cast<f32x4*>(sU + o * RW + c4 * 4) = wreg[v];                                 \
+      }                                                                                            \
+    }                                                                                              \
+    if ((OC) == 0) {                                                                               \
+      if (tid < KIS * nk) sK[k0f * kKnotPad + k0k] = kreg0;                                        \
+      if (tid + 256 < KIS * nk) sK[k1f * kKnotPad + k1k] = kreg1;                                  \
+    }                                                                                              \
+    /* next W tile: next output chunk of this slab, or the first of the next slab */               \
+    if ((OC) + 1 < OT) {                                                                           \
+      PDEKAN_FETCH_W(i0, (OC) + 1)                                                                 \
+    } else if (i0 + KIS < I) {                                                                     \
+      PDEKAN_FETCH_W(i0 + KIS, 0)                                                                  \
+      PDEKAN_FETCH_KNOTS(i0 + KIS)                                                                 \
+    }                                                                                              \
+    if ((OC) == OT - 1) {                                                                          \
+      _Pragma("unroll") for (int v = 0; v < NP; ++v) {                                             \
+        const int pair = lane + 64 * v;                                                            \
+        int64_t pc = PW0 + (pair & 7);                                                             \
+        if (pc > N - 1) pc = N - 1;                                                                \
+        const int f = (pair >> 3) < KIS ? (pair >> 3) : 0;                                         \
+        jete[v] = *reinterpret_cast<const f32x4*>(a + pc * I + i0 + f);                            \
+      }                                                                                            \
+    }                                                                                              \
+    __syncthreads();                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 16; ++t) { /* full: afrag needs constant indices */     \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                             \
+        const float bv = sU[(4 * t + q) * RW + n * 16 + l15];                                      \
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][0][t], bv, acc[0][n], 0, 0, 0); \
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][1][t], bv, acc[1][n], 0, 0, 0); \
+      }                                                                                            \
+    }                                                                                              \
+  }
+    PDEKAN_CHUNK(0)
+    if constexpr (OT > 1) PDEKAN_CHUNK(1)
+    if constexpr (OT > 2) { PDEKAN_CHUNK(2) PDEKAN_CHUNK(3) }
+
+    __syncthreads();                                      // every wave is done with the W tile
     float4* sS = reinterpret_cast<float4*>(sU) + wave * 8 * COLS;     // [8][COLS] float4
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -314,11 +420,13 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
       for (int n = 0; n < NT; ++n)
         sS[(mt * 4 + q) * COLS + n * 16 + l15] = make_float4(acc[mt][n][0], acc[mt][n][1], acc[mt][n][2], acc[mt][n][3]);
     __syncthreads();
-    for (int pair = lane; pair < 8 * KIS; pair += 64) {
+#pragma unroll
+    for (int v = 0; v < NP; ++v) {
+      const int pair = lane + 64 * v;
       const int p_local = pair & 7, f_local = pair >> 3;
       const int64_t p = PW0 + p_local;
-      if (p < N) {
-        const float4 jet = a[p * I + i0 + f_local];
+      if (f_local < KIS && p < N) {
+        const float4 jet = make_float4(jete[v][0], jete[v][1], jete[v][2], jete[v][3]);
         Basis bs;
         eval_basis<true>(sK + f_local * kKnotPad, nk, jet.x, bs);
         const Act av = eval_act(act, jet.x);
@@ -348,6 +456,10 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
     }
   }
 }
+
+#undef PDEKAN_CHUNK
+#undef PDEKAN_FETCH_W
+#undef PDEKAN_FETCH_KNOTS
 
 // ==========================================================================
 // host side
@@ -391,7 +503,7 @@ static void allow_big_lds(Kern k, size_t bytes) {
 template <int C1, int KI>
 static void fwd_launch(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
   constexpr int KK = KI * C1;
-  const size_t lds = (size_t)(5 * KK * 64 + KI * kKnotPad) * 4;
+  const size_t lds = (size_t)(5 * KK * 64 + 2 * KI * kKnotPad) * 4;
   auto k = fwd_mfma_kernel<C1, KI>;
   allow_big_lds(k, lds);
   dim3 g((unsigned)((N + 63) / 64), L.O / 64);
@@ -404,14 +516,14 @@ void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float*
   else fwd_launch<9, 4>(L, a, wt, y, N, st);
 }
 
-template <int C1, int KIW>
+template <int C1, int KIW, int PB>
 static void bww_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
                        hipStream_t st) {
-  constexpr int COLS = KIW * C1, PB = 64 / KIW, ROWS = PB * 4, RS = ROWS + 4;
+  constexpr int COLS = KIW * C1, ROWS = PB * 4, RS = ROWS + 4;
   const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
   int64_t chunk = (N + nchunks - 1) / nchunks;
   chunk = (chunk + PB - 1) / PB * PB;
-  auto k = bwd_weight_mfma_kernel<C1, KIW>;
+  auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
   allow_big_lds(k, lds);
   dim3 g(L.I / (4 * KIW), L.O / 64, nchunks);
   k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy), L.grid, part, N, L.I,
@@ -420,9 +532,9 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
                             hipStream_t st) {
-  if (L.G == 10) bww_launch<14, 8>(L, a, gy, part, nchunks, N, st);
-  else if (L.G == 20) bww_launch<24, 4>(L, a, gy, part, nchunks, N, st);
-  else bww_launch<9, 16>(L, a, gy, part, nchunks, N, st);
+  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st);
+  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st);
+  else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
 }
 
 template <int C1, int KIS, int OT>
