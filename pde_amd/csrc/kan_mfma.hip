@@ -45,22 +45,40 @@ __device__ __forceinline__ void expand_jets(const float* knots, int nk, int act,
   c0 = bs.c0;
 }
 
-// Write one feature's C1 columns of the E tile, layout tile[col][RS] with the 4
-// jets of local point p at [col][4p .. 4p+3] (one 16-byte store per column).
+// E tile layout: tile[col][RS] with the 4 jets of local point p at [col][4p .. 4p+3].
+// A lane owns the same strip (feature slot f_local, point p_local) of the tile in
+// every slab / pass, so after one full zero-fill it only has to clear the 4 columns
+// it wrote last time and write the 4 live columns + the base column of this time:
+// 9 unconditional 16-byte stores (a column outside [0, C) is redirected to the
+// lane's private dump slot instead of being branched around).
+template <int C1>
+__device__ __forceinline__ void zero_strip(float* tile, int RS, int f_local, int p_local) {
+  float* base = tile + (f_local * C1) * RS + p_local * 4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < C1; ++c) *reinterpret_cast<float4*>(base + c * RS) = zero;
+}
+
 template <int C1>
 __device__ __forceinline__ void write_expanded(float* tile, int RS, int f_local, int p_local,
-                                               const float4 (&e)[5], int c0) {
+                                               const float4 (&e)[5], int c0, int& prev_c0, float* dump) {
   constexpr int C = C1 - 1;
   float* base = tile + (f_local * C1) * RS + p_local * 4;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(base + c * RS) = zero;
+  for (int m = 0; m < 4; ++m) {
+    const int c = prev_c0 + m;
+    float* dst = (c >= 0 && c < C) ? base + c * RS : dump;
+    *reinterpret_cast<float4*>(dst) = zero;
+  }
   *reinterpret_cast<float4*>(base + C * RS) = e[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int c = c0 + m;
-    if (c >= 0 && c < C) *reinterpret_cast<float4*>(base + c * RS) = e[m];
+    float* dst = (c >= 0 && c < C) ? base + c * RS : dump;
+    *reinterpret_cast<float4*>(dst) = e[m];
   }
+  prev_c0 = c0;
 }
 
 // register <-> memory helpers (plain functions: arrays captured by a lambda end up in scratch)
@@ -103,6 +121,7 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
   float* sW = reinterpret_cast<float*>(smem);            // [KK][64]
   float* sA = sW + KK * 64;                              // [4][KK][64]
   float* sK = sA + 4 * KK * 64;                          // [2][KI][kKnotPad]
+  float* sD = sK + 2 * KI * kKnotPad;                    // [256][4] dump slots
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p_local = lane & 15, f_local = lane >> 4;
@@ -122,6 +141,8 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
   const bool gen_lane = f_local < KI;
 
   if (knot_thread) sK[kf * kKnotPad + kk_] = grid[(size_t)kf * nk + kk_];
+  if (gen_lane) zero_strip<C1>(tileA, 64, f_local, p_local);
+  int prev_c0 = -100;
   fetch_rows16<WV, KK * 16>(wreg, wsrc, O, tid);
   if (gen_lane) jet = a[pj * I + f_local];
   if (KI < I && knot_thread) kreg = grid[(size_t)(KI + kf) * nk + kk_];
@@ -138,7 +159,7 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
       float4 e[5];
       int c0;
       expand_jets(sK + (s & 1) * KI * kKnotPad + f_local * kKnotPad, nk, act, jet, e, c0);
-      write_expanded<C1>(tileA, 64, f_local, p_local, e, c0);
+      write_expanded<C1>(tileA, 64, f_local, p_local, e, c0, prev_c0, sD + tid * 4);
     }
     if (more) {
       fetch_rows16<WV, KK * 16>(wreg, wsrc + (size_t)(i0 + KI) * C1 * O, O, tid);
@@ -146,15 +167,23 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
       if (i0 + 2 * KI < I && knot_thread) kreg = grid[(size_t)(i0 + 2 * KI + kf) * nk + kk_];
     }
     __syncthreads();
-#pragma unroll 4
+    // operands are read from LDS one k-step ahead of the MFMAs that consume them
+    float fa0[2], fa1[2], fb0[2], fb1[2];
+    fa0[0] = tileA[h * 64 + r]; fa1[0] = tileA[h * 64 + 32 + r];
+    fb0[0] = sW[h * 64 + r];    fb1[0] = sW[h * 64 + 32 + r];
+#pragma unroll
     for (int t = 0; t < KK / 2; ++t) {
-      const int kk = 2 * t + h;
-      const float a0 = tileA[kk * 64 + r], a1 = tileA[kk * 64 + 32 + r];
-      const float b0 = sW[kk * 64 + r], b1 = sW[kk * 64 + 32 + r];
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      const int cur = t & 1, nxt = cur ^ 1;
+      if (t + 1 < KK / 2) {
+        const int kk = 2 * (t + 1) + h;
+        fa0[nxt] = tileA[kk * 64 + r]; fa1[nxt] = tileA[kk * 64 + 32 + r];
+        fb0[nxt] = sW[kk * 64 + r];    fb1[nxt] = sW[kk * 64 + 32 + r];
+      }
+      __builtin_amdgcn_sched_barrier(0);                 // keep the reads ahead of the MFMAs
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb0[cur], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb1[cur], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb0[cur], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb1[cur], acc11, 0, 0, 0);
     }
   }
   // rows 8g+4h .. +3 of an m-tile are the 4 jets of local point 2g+h (+8 per m-tile)
@@ -211,6 +240,8 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
     const int f = idx / nk, k = idx - f * nk;
     sK[f * kKnotPad + k] = grid[(size_t)(blockIdx.x * 4 * KIW + f) * nk + k];
   }
+  if (gen_lane) zero_strip<C1>(tileE, RS, f_local, p_local);
+  int prev_c0 = -100;
   f32x4 acc[NT][4];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -253,21 +284,32 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
       float4 e[5];
       int c0;
       expand_jets(sK + (wave * KIW + f_local) * kKnotPad, nk, act, jet, e, c0);
-      write_expanded<C1>(tileE, RS, f_local, p_local, e, c0);
+      // dump slot: the 4 pad floats that end the first row of this lane's strip
+      write_expanded<C1>(tileE, RS, f_local, p_local, e, c0, prev_c0, tileE + (f_local * C1) * RS + ROWS);
     }
     if (pb + PB < pend) PDEKAN_BWW_FETCH(pb + PB)
     __syncthreads();
-#pragma unroll 2
+    // operands of point t+1 are read while the MFMAs of point t run
+    float fb[2][4], fe[2][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fb[0][m] = sG[q * RG + m * 16 + l15];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fe[0][n] = tileE[(n * 16 + l15) * RS + q];
+#pragma unroll
     for (int t = 0; t < PB; ++t) {
-      float b[4];
+      const int cur = t & 1, nxt = cur ^ 1;
+      if (t + 1 < PB) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) b[m] = sG[(4 * t + q) * RG + m * 16 + l15];
+        for (int m = 0; m < 4; ++m) fb[nxt][m] = sG[(4 * (t + 1) + q) * RG + m * 16 + l15];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float av = tileE[(n * 16 + l15) * RS + 4 * t + q];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[m], acc[n][m], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) fe[nxt][n] = tileE[(n * 16 + l15) * RS + 4 * (t + 1) + q];
       }
+      __builtin_amdgcn_sched_barrier(0);                 // keep the reads ahead of the MFMAs
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fe[cur][n], fb[cur][m], acc[n][m], 0, 0, 0);
     }
   }
 #undef PDEKAN_BWW_FETCH
@@ -400,11 +442,18 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
       }                                                                                            \
     }                                                                                              \
     __syncthreads();                                                                               \
+    /* W operands of step t+1 are read while the MFMAs of step t run */                           \
+    float fw[2][NT];                                                                               \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) fw[0][n] = sU[q * RW + n * 16 + l15];           \
     _Pragma("unroll") for (int t = 0; t < 16; ++t) { /* full: afrag needs constant indices */     \
+      if (t + 1 < 16) {                                                                            \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                             \
+          fw[(t + 1) & 1][n] = sU[(4 * (t + 1) + q) * RW + n * 16 + l15];                          \
+      }                                                                                            \
+      __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the MFMAs */                   \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                             \
-        const float bv = sU[(4 * t + q) * RW + n * 16 + l15];                                      \
-        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][0][t], bv, acc[0][n], 0, 0, 0); \
-        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][1][t], bv, acc[1][n], 0, 0, 0); \
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][0][t], fw[t & 1][n], acc[0][n], 0, 0, 0); \
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[OC][1][t], fw[t & 1][n], acc[1][n], 0, 0, 0); \
       }                                                                                            \
     }                                                                                              \
   }
@@ -503,7 +552,7 @@ static void allow_big_lds(Kern k, size_t bytes) {
 template <int C1, int KI>
 static void fwd_launch(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
   constexpr int KK = KI * C1;
-  const size_t lds = (size_t)(5 * KK * 64 + 2 * KI * kKnotPad) * 4;
+  const size_t lds = (size_t)(5 * KK * 64 + 2 * KI * kKnotPad + 256 * 4) * 4;
   auto k = fwd_mfma_kernel<C1, KI>;
   allow_big_lds(k, lds);
   dim3 g((unsigned)((N + 63) / 64), L.O / 64);
