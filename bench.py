@@ -62,6 +62,9 @@ def kernel_cost(name, widths, grid, n_pts, J):
         byts = 4.0 * J * (2 * I + O) * n_pts
     elif kind == "bwd_weight":
         byts = 4.0 * J * (I + O) * n_pts
+    elif kind == "head_fused":              # last layer fwd + residual + loss + its bwd in one pass
+        flops = 3.0 * flops
+        byts = 4.0 * (J * 2 * I + widths[0]) * n_pts
     else:                                   # reduce_unpack: O(parameters)
         return 0.0, 0.0
     return flops, byts
