@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip the AdamW update")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank, to exercise the all-reduce path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,9 +111,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from pde_amd import KAN, _lib
@@ -134,7 +139,7 @@ def main():
 
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     step = BlackScholesStep(model, micro_batch=args.micro_batch)
-    dp = DataParallelStep(step, dist) if world > 1 else None
+    dp = DataParallelStep(step, dist) if dist is not None else None
     opt = torch.optim.AdamW(model.parameters(), lr=0.01)   # run1.py:209
 
     def one_step():

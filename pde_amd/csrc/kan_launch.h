@@ -46,6 +46,14 @@ void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, i
                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                     float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st);
 
+// kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
+bool sparse_eligible(int D, int D2, const LayerView& L);
+size_t sparse_table_floats(const LayerView& L);
+void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st);
+void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st);
+void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
+                             int64_t N, hipStream_t st);
+
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);
 int mfma_weight_chunks(int64_t N, const LayerView& L);

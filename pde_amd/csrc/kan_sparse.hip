@@ -1,0 +1,351 @@
+// Sparse-support VALU kernels for hidden KAN layers on gfx950, J = 4 jets
+// (value, d/dS, d/dt, d2/dS2): forward and input-jet gradients.
+//
+// Of the C+1 = G+4 columns a feature contributes to the contraction
+// (efficient_kan/kan.py:153-166), only the 4 cubic bases whose support holds x
+// and the base-activation column are non-zero for a given point.  A dense GEMM
+// multiplies the other G-1 columns by zero; on gfx950 the fp32 MFMA runs at the
+// fp32 VECTOR rate, so skipping them on the VALU is a net win: 5/(G+4) of the
+// multiply-adds (2.8x fewer at G = 10).
+//
+// Lane = (point, group of 32 outputs).  A lane evaluates the basis of its
+// (point, feature) once, finds the interval index s of x and then needs, per
+// output, the 4 consecutive spline weights w[o][i][s-3 .. s]: these come from a
+// "window table" in LDS laid out [output][slot s][4 weights] - 16 slots x 16 B =
+// one 256-byte bank row per output, so the 16 lanes of a ds_read_b128 group hit
+// either the same slot (broadcast) or different banks: conflict-free whatever
+// the data.  The table of feature i+1 is staged (global -> registers -> LDS,
+// double-buffered) while feature i is being consumed.
+//
+//   forward:      y[p][o][:]     += sum_m w[o][i][s-3+m] * E_m[:] + w_b[o][i] * E_b[:]
+//   input grads:  G_m[:]          = sum_o w[o][i][s-3+m] * gy[p][o][:]   (+ base), then the
+//                 chain rule through B', B'', B''' exactly as in the streaming kernel
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "kan_math.h"
+#include "kan_launch.h"
+
+namespace pdekan {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSlots = 16;          // interval slots per (output, feature) row: needs G + 6 <= 16
+constexpr int kKnotPadS = 28;
+
+// wp[O][I][C1] -> win[I][O][16][4] (window of 4 spline weights per interval slot), wbt[I][O]
+__global__ void pack_window_kernel(const float* __restrict__ wp, float* __restrict__ win,
+                                   float* __restrict__ wbt, int I, int O, int C) {
+  const int C1 = C + 1;
+  const int total = I * O * kSlots;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int slot = t % kSlots;
+    const int o = (t / kSlots) % O;
+    const int i = t / (kSlots * O);
+    const float* w = wp + ((size_t)o * I + i) * C1;
+    f32x4 v;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = slot - 3 + m;
+      v[m] = (c >= 0 && c < C) ? w[c] : 0.0f;
+    }
+    *reinterpret_cast<f32x4*>(win + (size_t)t * 4) = v;
+    if (slot == 0) wbt[(size_t)i * O + o] = w[C];
+  }
+}
+
+// Basis and activation of one (point, feature) for the sparse kernels.
+struct Live {
+  f32x4 b, d1, d2, d3;   // the 4 live bases and derivatives
+  Act act;
+  int slot;              // interval index s, clamped to [0, kSlots)
+};
+
+template <bool kNeedD3>
+__device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_kind, float x) {
+  Basis bs;
+  eval_basis<kNeedD3>(knots, nk, x, bs);
+  Live L;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { L.b[m] = bs.b[m]; L.d1[m] = bs.d1[m]; L.d2[m] = bs.d2[m]; L.d3[m] = bs.d3[m]; }
+  L.act = eval_act(act_kind, x);
+  int s = bs.c0 + 3;
+  s = s < 0 ? 0 : (s > kSlots - 1 ? kSlots - 1 : s);
+  L.slot = s;
+  return L;
+}
+
+// --------------------------------------------------------------------------
+// shared staging of the per-feature tables: O*64 floats of windows + O base weights
+// --------------------------------------------------------------------------
+template <int O>
+struct TableRegs {
+  static constexpr int NV = (O * 16) / 256;     // float4 per thread: O*64 floats / (256 threads * 4)
+  f32x4 v[NV];
+  float base;
+};
+
+template <int O>
+__device__ __forceinline__ void table_fetch(TableRegs<O>& r, const float* win, const float* wbt, int i, int tid) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(win + (size_t)i * O * 64);
+#pragma unroll
+  for (int k = 0; k < TableRegs<O>::NV; ++k) r.v[k] = src[tid + k * 256];
+  r.base = wbt[(size_t)i * O + (tid < O ? tid : 0)];
+}
+
+template <int O>
+__device__ __forceinline__ void table_store(const TableRegs<O>& r, float* sT, float* sB, int tid) {
+  f32x4* dst = reinterpret_cast<f32x4*>(sT);
+#pragma unroll
+  for (int k = 0; k < TableRegs<O>::NV; ++k) dst[tid + k * 256] = r.v[k];
+  if (tid < O) sB[tid] = r.base;
+}
+
+// ==========================================================================
+// forward
+// ==========================================================================
+template <int O>
+__global__ void __launch_bounds__(256, 2)
+fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ win,
+                  const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act) {
+  constexpr int OG = O / 32;              // output groups = lanes per point
+  constexpr int PW = 64 / OG;             // points per wave
+  const int nk = G + 7;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = reinterpret_cast<float*>(smem);            // [2][O*64]
+  float* sB = sT + 2 * O * 64;                           // [2][O]
+  float* sK = sB + 2 * O;                                // [I][kKnotPadS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane / PW, pl = lane % PW;
+  int64_t p = ((int64_t)blockIdx.x * 4 + wave) * PW + pl;
+  const bool live_pt = p < N;
+  if (!live_pt) p = N - 1;
+
+  for (int t = tid; t < I * nk; t += 256) sK[(t / nk) * kKnotPadS + t % nk] = grid[t];
+  TableRegs<O> tr;
+  table_fetch<O>(tr, win, wbt, 0, tid);
+  table_store<O>(tr, sT, sB, tid);
+  if (I > 1) table_fetch<O>(tr, win, wbt, 1, tid);
+
+  f32x4 acc[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 jet = *reinterpret_cast<const f32x4*>(a + (p * I) * 4);
+
+  for (int i = 0; i < I; ++i) {
+    __syncthreads();                       // table i visible; buffer (i+1)&1 free
+    const int buf = i & 1;
+    if (i + 1 < I) {
+      table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
+      if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
+    }
+    const f32x4 cur = jet;
+    if (i + 1 < I) jet = *reinterpret_cast<const f32x4*>(a + (p * I + i + 1) * 4);
+    const Live L = eval_live<false>(sK + i * kKnotPadS, nk, act, cur[0]);
+    const float s2 = cur[1] * cur[1];
+    // expanded jets of the 4 live splines and of the base column
+    f32x4 e[5];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      e[m] = (f32x4){L.b[m], L.d1[m] * cur[1], L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
+    e[4] = (f32x4){L.act.f0, L.act.f1 * cur[1], L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
+    const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
+    const float* bb = sB + buf * O + g * 32;
+    // outputs in groups of 4; the weights of group q+1 are read from LDS while group q is consumed
+    f32x4 wq[2][4], bq[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(tb + k * 64);
+    bq[0] = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q + 1 < 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wq[nxt][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 1) * 4 + k) * 64);
+        bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 1) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 w = wq[cur][k];
+        f32x4 t = acc[q * 4 + k];         // one fma chain per accumulator: 5 x (2 packed fmas)
+        t += w[0] * e[0];
+        t += w[1] * e[1];
+        t += w[2] * e[2];
+        t += w[3] * e[3];
+        t += bq[cur][k] * e[4];
+        acc[q * 4 + k] = t;
+      }
+    }
+  }
+  if (live_pt) {
+    f32x4* dst = reinterpret_cast<f32x4*>(y + (p * O + g * 32) * 4);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) dst[o] = acc[o];
+  }
+}
+
+// ==========================================================================
+// input-jet gradients
+// ==========================================================================
+template <int O>
+__global__ void __launch_bounds__(256, 2)
+bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
+                        const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
+                        int64_t N, int I, int G, int act) {
+  constexpr int OG = O / 32;
+  constexpr int PW = 64 / OG;
+  const int nk = G + 7;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = reinterpret_cast<float*>(smem);
+  float* sB = sT + 2 * O * 64;
+  float* sK = sB + 2 * O;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane / PW, pl = lane % PW;
+  int64_t p = ((int64_t)blockIdx.x * 4 + wave) * PW + pl;
+  const bool live_pt = p < N;
+  if (!live_pt) p = N - 1;
+
+  for (int t = tid; t < I * nk; t += 256) sK[(t / nk) * kKnotPadS + t % nk] = grid[t];
+  TableRegs<O> tr;
+  table_fetch<O>(tr, win, wbt, 0, tid);
+  table_store<O>(tr, sT, sB, tid);
+  if (I > 1) table_fetch<O>(tr, win, wbt, 1, tid);
+
+  // cotangents of this lane's 32 outputs stay in registers for the whole kernel
+  f32x4 gyr[32];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(gy + (p * O + g * 32) * 4);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) gyr[o] = src[o];
+  }
+  f32x4 jet = *reinterpret_cast<const f32x4*>(a + (p * I) * 4);
+
+  for (int i = 0; i < I; ++i) {
+    __syncthreads();
+    const int buf = i & 1;
+    if (i + 1 < I) {
+      table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
+      if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
+    }
+    const f32x4 cur = jet;
+    if (i + 1 < I) jet = *reinterpret_cast<const f32x4*>(a + (p * I + i + 1) * 4);
+    const Live L = eval_live<true>(sK + i * kKnotPadS, nk, act, cur[0]);
+    const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
+    const float* bb = sB + buf * O + g * 32;
+    f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = G0, G2 = G0, G3 = G0, Gb = G0;
+    f32x4 wq[2][4], bq[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(tb + k * 64);
+    bq[0] = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cw = q & 1, nw = cw ^ 1;
+      if (q + 1 < 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wq[nw][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 1) * 4 + k) * 64);
+        bq[nw] = *reinterpret_cast<const f32x4*>(bb + (q + 1) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 w = wq[cw][k];
+        const f32x4 gv = gyr[q * 4 + k];
+        G0 += w[0] * gv; G1 += w[1] * gv; G2 += w[2] * gv; G3 += w[3] * gv;
+        Gb += bq[cw][k] * gv;
+      }
+    }
+    // chain rule on this lane's partial sums (linear in G, so it commutes with the sum over groups)
+    const float s2 = cur[1] * cur[1];
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 Gm[5] = {G0, G1, G2, G3, Gb};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const float e1 = m < 4 ? L.d1[m & 3] : L.act.f1;
+      const float e2 = m < 4 ? L.d2[m & 3] : L.act.f2;
+      const float e3 = m < 4 ? L.d3[m & 3] : L.act.f3;
+      const f32x4 q = Gm[m];
+      out[0] += q[0] * e1 + (q[1] * cur[1] + q[2] * cur[2]) * e2 + q[3] * (s2 * e3 + cur[3] * e2);
+      out[1] += q[1] * e1 + 2.0f * cur[1] * q[3] * e2;
+      out[2] += q[2] * e1;
+      out[3] += q[3] * e1;
+    }
+    // add the output groups of one point (lanes pl, pl+PW, ...)
+#pragma unroll
+    for (int off = PW; off < 64; off <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] += __shfl_xor(out[j], off);
+    }
+    if (g == 0 && live_pt) *reinterpret_cast<f32x4*>(ga + (p * I + i) * 4) = out;
+  }
+}
+
+// ==========================================================================
+// host side
+// ==========================================================================
+bool sparse_eligible(int D, int D2, const LayerView& L) {
+  if (D != 2 || D2 != 1) return false;
+  const char* off = getenv("PDEKAN_DISABLE_SPARSE");
+  if (off && off[0] == '1') return false;
+  if (L.G + 6 > kSlots) return false;
+  if (L.O != 64 && L.O != 128) return false;
+  if (L.I < 8 || L.I > 256) return false;
+  return true;
+}
+
+size_t sparse_table_floats(const LayerView& L) { return (size_t)L.I * L.O * (kSlots * 4 + 1); }
+
+void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st) {
+  const int total = L.I * L.O * kSlots;
+  int blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  pack_window_kernel<<<blocks, 256, 0, st>>>(wp, win, win + (size_t)L.I * L.O * kSlots * 4, L.I, L.O, L.C());
+}
+
+template <int O>
+static size_t sparse_lds(const LayerView& L) {
+  return (size_t)(2 * O * 64 + 2 * O + L.I * kKnotPadS) * 4;
+}
+
+template <typename Kern>
+static void big_lds(Kern k, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
+  const float* wbt = win + (size_t)L.I * L.O * kSlots * 4;
+  if (L.O == 64) {
+    const int pts = 4 * 32;
+    auto k = fwd_sparse_kernel<64>;
+    const size_t lds = sparse_lds<64>(L);
+    big_lds(k, lds);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, win, wbt, y, N, L.I, L.G, L.act);
+  } else {
+    const int pts = 4 * 16;
+    auto k = fwd_sparse_kernel<128>;
+    const size_t lds = sparse_lds<128>(L);
+    big_lds(k, lds);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, win, wbt, y, N, L.I, L.G, L.act);
+  }
+}
+
+void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
+                             int64_t N, hipStream_t st) {
+  const float* wbt = win + (size_t)L.I * L.O * kSlots * 4;
+  if (L.O == 64) {
+    const int pts = 4 * 32;
+    auto k = bwd_input_sparse_kernel<64>;
+    const size_t lds = sparse_lds<64>(L);
+    big_lds(k, lds);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, win, wbt, ga, N, L.I, L.G, L.act);
+  } else {
+    const int pts = 4 * 16;
+    auto k = bwd_input_sparse_kernel<128>;
+    const size_t lds = sparse_lds<128>(L);
+    big_lds(k, lds);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, win, wbt, ga, N, L.I, L.G, L.act);
+  }
+}
+
+}  // namespace pdekan

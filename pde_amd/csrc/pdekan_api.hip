@@ -89,14 +89,22 @@ int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }
 
-size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
-  const size_t packed = align_up(L.packed_floats() * 4) / 4;
-  return 2 * packed + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4;
+size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
+  return pdekan::sparse_eligible(D, D2, L) ? pdekan::sparse_table_floats(L) : 0;
 }
 
-int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, float* y, int64_t n,
-                hipStream_t st, int li = 0) {
-  if (pdekan::mfma_eligible(D, D2, L)) {
+size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  const size_t packed = align_up(L.packed_floats() * 4) / 4;
+  return 2 * packed + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4 +
+         align_up(win_floats(D, D2, L) * 4) / 4;
+}
+
+int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
+                float* y, int64_t n, hipStream_t st, int li = 0) {
+  if (win && pdekan::sparse_eligible(D, D2, L)) {
+    ProfScope ps(st, "L%d.fwd.sparse", li);
+    pdekan::launch_fwd_sparse(L, a, win, y, n, st);
+  } else if (pdekan::mfma_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.mfma", li);
     pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
   } else {
@@ -108,8 +116,8 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
 }
 
 int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* gy, const float* wp,
-                 float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st,
-                 int li = 0) {
+                 const float* win, float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
+                 hipStream_t st, int li = 0) {
   const bool mf = pdekan::mfma_eligible(D, D2, L);
   if (g) {
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
@@ -128,7 +136,10 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
                                  L.scaler ? g->spline_scaler : nullptr, accumulate, st);
   }
   if (ga) {
-    if (mf) {
+    if (win && pdekan::sparse_eligible(D, D2, L)) {
+      ProfScope ps(st, "L%d.bwd_input.sparse", li);
+      pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st);
+    } else if (mf) {
       ProfScope ps(st, "L%d.bwd_input.mfma", li);
       pdekan::launch_bwd_input_mfma(L, a, gy, wp, ga, n, st);
     } else {
@@ -176,7 +187,7 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
 }
 
 struct ModelWs {
-  std::vector<float*> wp, wt, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
+  std::vector<float*> wp, wt, win, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
   float* g[2];
   float* part;
   float* loss_part;
@@ -192,8 +203,14 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     total += align_up(floats * 4);
     return ws ? c.take(floats) : nullptr;
   };
-  W.wp.resize(nl); W.wt.resize(nl); W.act.resize(nl + 1);
-  for (size_t l = 0; l < nl; ++l) { W.wp[l] = take(P.L[l].packed_floats()); W.wt[l] = take(P.L[l].packed_floats()); }
+  W.wp.resize(nl); W.wt.resize(nl); W.win.resize(nl); W.act.resize(nl + 1);
+  for (size_t l = 0; l < nl; ++l) {
+    W.wp[l] = take(P.L[l].packed_floats());
+    W.wt[l] = take(P.L[l].packed_floats());
+    const size_t wf = win_floats(P.D, P.D2, P.L[l]);
+    W.win[l] = wf ? take(wf) : nullptr;
+    if (!ws && wf) W.win[l] = reinterpret_cast<float*>(1);   // sizing pass: only the total matters
+  }
   for (size_t l = 0; l <= nl; ++l) {
     const int w = (l < nl) ? P.L[l].I : P.L[nl - 1].O;
     W.act[l] = take((size_t)P.mb * w * P.J);
@@ -240,10 +257,13 @@ int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_
   Carver c(ws, ws_bytes);
   float* wp = c.take(L.packed_floats());
   float* wt = c.take(L.packed_floats());
+  const size_t wf = win_floats(n_dir, n_second, L);
+  float* win = wf ? c.take(wf) : nullptr;
   if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   pdekan::launch_pack_weights(L, wp, wt, st);
-  return run_forward(n_dir, n_second, L, x_jet, wt, y_jet, n, st);
+  if (win) pdekan::launch_pack_window(L, wp, win, st);
+  return run_forward(n_dir, n_second, L, x_jet, wt, win, y_jet, n, st);
 }
 
 int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const float* gy_jet, int64_t n,
@@ -259,10 +279,13 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   float* wp = c.take(L.packed_floats());
   float* wt = c.take(L.packed_floats());
   float* part = c.take((size_t)(weight_chunks(n_dir, n_second, L, n) + 1) * L.packed_floats());
+  const size_t wf = (gx_jet != nullptr) ? win_floats(n_dir, n_second, L) : 0;
+  float* win = wf ? c.take(wf) : nullptr;
   if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   pdekan::launch_pack_weights(L, wp, wt, st);
-  return run_backward(n_dir, n_second, L, x_jet, gy_jet, wp, gx_jet, part, grads, accumulate, n, st);
+  if (win) pdekan::launch_pack_window(L, wp, win, st);
+  return run_backward(n_dir, n_second, L, x_jet, gy_jet, wp, win, gx_jet, part, grads, accumulate, n, st);
 }
 
 size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers, int64_t n, int32_t n_dir,
@@ -288,14 +311,17 @@ int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const 
   if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
-  for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+  for (int l = 0; l < nl; ++l) {
+    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+    if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
+  }
   const int out_w = P.L[nl - 1].O;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
     const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
     pdekan::launch_seed_jets(P.D, P.D2, x + p0 * stride_n, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out_jet + p0 * out_w * P.J : W.act[l + 1];
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], dst, m, st, l);
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l);
       if (rc) return rc;
     }
   }
@@ -322,7 +348,10 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   const float inv_n = 1.0f / (float)n_global;
   {
     ProfScope ps(st, "pack_weights", 0);
-    for (int l = 0; l < nl; ++l) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+    for (int l = 0; l < nl; ++l) {
+      pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+      if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
+    }
   }
   bool first = true;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
@@ -336,7 +365,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     const bool fused_head = pdekan::head_eligible(P.D, H) && !getenv_flag("PDEKAN_DISABLE_FUSED_HEAD");
     const int n_fwd = fused_head ? nl - 1 : nl;
     for (int l = 0; l < n_fwd; ++l) {
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.act[l + 1], m, st, l);
+      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], W.act[l + 1], m, st, l);
       if (rc) return rc;
     }
     const float* tgt = target ? target + p0 : nullptr;
@@ -374,7 +403,8 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     if (grads) {
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
-        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], gnext, W.part, &grads[l], acc_flag, m, st, l);
+        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, &grads[l], acc_flag,
+                          m, st, l);
         if (rc) return rc;
         cur ^= 1;
       }

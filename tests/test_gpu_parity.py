@@ -265,3 +265,33 @@ def test_single_layer_model_step():
     flat = torch.cat([ref["grads"][0][k].flatten() for k in ("base_weight", "spline_weight", "spline_scaler")])
     assert abs(loss - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
     assert max_rel(step.flat_grad.cpu(), flat) <= TOL
+
+
+@pytest.mark.parametrize("disable", ["PDEKAN_DISABLE_SPARSE", "PDEKAN_DISABLE_MFMA", None])
+@pytest.mark.parametrize("widths,G,N", [([2, 64, 64, 1], 10, 333), ([2, 64, 128, 64, 1], 10, 200),
+                                        ([2, 64, 64, 1], 5, 129)])
+def test_hidden_layer_paths_match_oracle(widths, G, N, disable, monkeypatch):
+    """The same step through each hidden-layer path: sparse VALU forward/input
+    gradients (default where eligible), dense MFMA only, streaming only."""
+    from pde_amd.pinn import BlackScholesStep
+    if disable:
+        monkeypatch.setenv(disable, "1")
+    m = _random_model(widths, G, 31 + G + len(widths))
+    x = torch.rand(N, 2, generator=torch.Generator().manual_seed(6))
+    ref = O.pinn_step(x.double(), O.layers_from_state_dict(m.state_dict(), dtype=torch.float64), "silu")
+    m = m.cuda()
+    step = BlackScholesStep(m)
+    res = torch.empty(N, device="cuda")
+    loss = step(x.cuda(), residual_out=res).item()
+    assert max_rel(res.cpu(), ref["res"]) <= TOL
+    assert abs(loss - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    off = 0
+    for l in range(len(widths) - 1):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            n = ref["grads"][l][k].numel()
+            assert max_rel(step.flat_grad[off:off + n].cpu(), ref["grads"][l][k].flatten()) <= TOL, (l, k)
+            off += n
+    # forward_jet and autograd through it use the layer-level entry points
+    jet = m.forward_jet(x.cuda())
+    assert max_rel(jet[:, 0, 0].cpu(), ref["v"]) <= TOL
+    assert max_rel(jet[:, 0, 3].cpu(), ref["second"][:, 0]) <= TOL
