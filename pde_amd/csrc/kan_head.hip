@@ -22,7 +22,8 @@ namespace pdekan {
 template <int D, int D2, int NF>
 __global__ void __launch_bounds__(256)
 head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
-               const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ wp,
+               const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ ginfo,
+               const float* __restrict__ wp,
                float sigma, float rate, float inv_n, float* __restrict__ res_out, float* __restrict__ ga,
                float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G, int act) {
   constexpr int J = 1 + D + D2;
@@ -30,12 +31,16 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
   const int nw = blockDim.x >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_knots = reinterpret_cast<float*>(smem);        // [I][nk]
-  float* s_w = s_knots + I * nk;                          // [I][C1]
+  const int kr = nk + 1;                                  // knots + the feature's 1/h (0 = not equally spaced)
+  float* s_knots = reinterpret_cast<float*>(smem);        // [I][kr]
+  float* s_w = s_knots + I * kr;                          // [I][C1]
   float* s_acc = s_w + I * C1;                            // [nw][I][C1]
   float* s_loss = s_acc + nw * I * C1;                    // [nw]
 
-  for (int t = threadIdx.x; t < I * nk; t += blockDim.x) s_knots[t] = grid[t];
+  for (int t = threadIdx.x; t < I * kr; t += blockDim.x) {
+    const int f = t / kr, k = t - f * kr;
+    s_knots[t] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
+  }
   for (int t = threadIdx.x; t < I * C1; t += blockDim.x) s_w[t] = wp[t];
   for (int t = threadIdx.x; t < nw * I * C1; t += blockDim.x) s_acc[t] = 0.0f;
   __syncthreads();
@@ -61,7 +66,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
       const float* src = a + (p * I + ic) * J;
 #pragma unroll
       for (int j = 0; j < J; ++j) jet[f][j] = src[j];
-      eval_basis<true>(s_knots + ic * nk, nk, jet[f][0], bs[f]);
+      eval_basis_row<true>(s_knots + ic * kr, nk, jet[f][0], bs[f]);
       av[f] = eval_act(act, jet[f][0]);
       const float* w = s_w + ic * C1;
       const float wb = live ? w[C] : 0.0f;
@@ -171,11 +176,11 @@ static void head_launch(const LayerView& L, const float* a, const float* x, int6
                         const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                         float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
   const int nw = head_waves(L);
-  const size_t lds = ((size_t)L.I * L.nk() + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
+  const size_t lds = ((size_t)L.I * (L.nk() + 1) + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
   auto k = head_bs_kernel<D, D2, NF>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, wp, sigma, rate, inv_n, res, ga, part, loss_part,
+  k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, L.ginfo, wp, sigma, rate, inv_n, res, ga, part, loss_part,
                                    N, L.I, L.G, L.act);
 }
 

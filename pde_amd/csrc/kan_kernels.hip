@@ -22,8 +22,25 @@ struct __attribute__((aligned(16))) EdgeRec {
   int c0;                     // first live spline index (may be out of range)
 };
 
-__device__ __forceinline__ void load_knots_to_lds(float* s_knots, const float* grid, int count) {
-  for (int t = threadIdx.x; t < count; t += blockDim.x) s_knots[t] = grid[t];
+// Stage knot rows [nrows][nk] as LDS rows of nk+1 floats; the extra float is the
+// feature's 1/h (equally spaced knots) or 0.
+__device__ __forceinline__ void load_knots_to_lds(float* s_knots, const float* grid, const float* ginfo,
+                                                  int row0, int nrows, int I, int nk) {
+  const int kr = nk + 1;
+  for (int t = threadIdx.x; t < nrows * kr; t += blockDim.x) {
+    const int f = t / kr, k = t - f * kr;
+    const int fi = row0 + f;
+    float v = 0.0f;
+    if (fi < I) v = (k < nk) ? grid[(size_t)fi * nk + k] : (ginfo ? ginfo[fi] : 0.0f);
+    s_knots[t] = v;
+  }
+}
+
+// per feature: 1/h when its knots are equally spaced (see equal_spacing_inv_h), else 0
+// (e.g. a grid moved by update_grid, kan.py:168-215)
+__global__ void grid_info_kernel(const float* __restrict__ grid, float* __restrict__ ginfo, int I, int nk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < I) ginfo[i] = equal_spacing_inv_h(grid + (size_t)i * nk, nk);
 }
 
 // --------------------------------------------------------------------------
@@ -80,7 +97,7 @@ __global__ void seed_jets_kernel(const float* __restrict__ x, int64_t stride_n, 
 // --------------------------------------------------------------------------
 template <int D, int D2>
 __global__ void __launch_bounds__(256)
-fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid,
+fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                    const float* __restrict__ wt, float* __restrict__ y,
                    int64_t N, int I, int O, int G, int act, int PT, int NIC) {
   constexpr int J = 1 + D + D2;
@@ -89,7 +106,7 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid,
   EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);
   float* s_jet = reinterpret_cast<float*>(recs + PT * I);
   float* s_knots = s_jet + PT * I * J;
-  load_knots_to_lds(s_knots, grid, I * nk);
+  load_knots_to_lds(s_knots, grid, ginfo, 0, I, I, nk);
   __syncthreads();
 
   const int64_t p0 = (int64_t)blockIdx.x * PT;
@@ -102,7 +119,7 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid,
 #pragma unroll
     for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
     Basis bs;
-    eval_basis<false>(s_knots + i * nk, nk, jet[0], bs);
+    eval_basis_row<false>(s_knots + i * (nk + 1), nk, jet[0], bs);
     const Act av = eval_act(act, jet[0]);
     EdgeRec r;
 #pragma unroll
@@ -162,13 +179,13 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid,
 template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
-                         const float* __restrict__ grid, const float* __restrict__ wp,
+                         const float* __restrict__ grid, const float* __restrict__ ginfo, const float* __restrict__ wp,
                          float* __restrict__ ga, int64_t N, int I, int O, int G, int act) {
   constexpr int J = 1 + D + D2;
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_knots = reinterpret_cast<float*>(smem);
-  load_knots_to_lds(s_knots, grid, I * nk);
+  load_knots_to_lds(s_knots, grid, ginfo, 0, I, I, nk);
   __syncthreads();
   const int64_t total = N * I;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -179,7 +196,7 @@ bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < J; ++j) jet[j] = a[t * J + j];
     Basis bs;
-    eval_basis<true>(s_knots + i * nk, nk, jet[0], bs);
+    eval_basis_row<true>(s_knots + i * (nk + 1), nk, jet[0], bs);
     const Act av = eval_act(act, jet[0]);
     float Gm[5][J];
 #pragma unroll
@@ -246,7 +263,7 @@ struct BwTile { int TI, TO, PG, PT; };
 template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
-                          const float* __restrict__ grid, float* __restrict__ part,
+                          const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
                           int64_t N, int I, int O, int G, int act, int64_t chunk_pts, BwTile T) {
   constexpr int J = 1 + D + D2;
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
@@ -254,8 +271,8 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);                  // [PT][TI]
   float* s_jet = reinterpret_cast<float*>(recs + PT * TI);           // [PT][TI][J]
-  float* s_knots = s_jet + PT * TI * J;                              // [TI][nk]
-  float* s_acc = s_knots + TI * nk;                                  // [C1][256]
+  float* s_knots = s_jet + PT * TI * J;                              // [TI][nk+1]
+  float* s_acc = s_knots + TI * (nk + 1);                            // [C1][256]
 
   const int i0 = blockIdx.x * TI, o0 = blockIdx.y * TO;
   const int e = threadIdx.x % TE, pg = threadIdx.x / TE;
@@ -263,10 +280,7 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
   const int i = i0 + ti, o = o0 + to;
   const bool edge_live = (i < I) && (o < O);
 
-  for (int t = threadIdx.x; t < TI * nk; t += blockDim.x) {
-    const int fi = i0 + t / nk;
-    s_knots[t] = (fi < I) ? grid[fi * nk + t % nk] : 0.0f;
-  }
+  load_knots_to_lds(s_knots, grid, ginfo, i0, TI, I, nk);
   for (int c = 0; c < C1; ++c) s_acc[c * 256 + threadIdx.x] = 0.0f;
   __syncthreads();
 
@@ -283,7 +297,7 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
 #pragma unroll
         for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
         Basis bs;
-        eval_basis<false>(s_knots + t1 * nk, nk, jet[0], bs);
+        eval_basis_row<false>(s_knots + t1 * (nk + 1), nk, jet[0], bs);
         const Act av = eval_act(act, jet[0]);
         EdgeRec r;
 #pragma unroll
@@ -441,6 +455,10 @@ __global__ void loss_finish_kernel(const float* __restrict__ loss_part, int npar
 // --------------------------------------------------------------------------
 static inline int pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
 
+void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st) {
+  grid_info_kernel<<<(L.I + 63) / 64, 64, 0, st>>>(L.grid, ginfo, L.I, L.nk());
+}
+
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st) {
   const int total = L.O * L.I * (L.C() + 1);
   const int blocks = (total + 255) / 256;
@@ -468,9 +486,10 @@ static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y,
     if (NIC > cap) NIC = cap;
     if (NIC > 64) NIC = 64;
   }
-  const size_t lds = (size_t)PT * L.I * (sizeof(EdgeRec) + J * 4) + (size_t)L.I * L.nk() * 4;
+  const size_t lds = (size_t)PT * L.I * (sizeof(EdgeRec) + J * 4) + (size_t)L.I * (L.nk() + 1) * 4;
   const int64_t blocks = (N + PT - 1) / PT;
-  fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, wt, y, N, L.I, L.O, L.G, L.act, PT, NIC);
+  fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act, PT,
+                                                                NIC);
 }
 
 template <int D, int D2>
@@ -480,8 +499,9 @@ static void bwd_input_t(const LayerView& L, const float* a, const float* gy, con
   int64_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
-  const size_t lds = (size_t)L.I * L.nk() * 4;
-  bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, wp, ga, N, L.I, L.O, L.G, L.act);
+  const size_t lds = (size_t)L.I * (L.nk() + 1) * 4;
+  bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, L.ginfo, wp, ga, N, L.I, L.O, L.G,
+                                                                 L.act);
 }
 
 static inline int pow2_ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
@@ -516,9 +536,10 @@ static void bwd_weight_t(const LayerView& L, const float* a, const float* gy, fl
   int64_t chunk = (N + nchunks - 1) / nchunks;
   chunk = (chunk + T.PT - 1) / T.PT * T.PT;
   dim3 g((L.I + T.TI - 1) / T.TI, (L.O + T.TO - 1) / T.TO, nchunks);
-  const size_t lds = sizeof(EdgeRec) * T.PT * T.TI + (size_t)T.PT * T.TI * J * 4 + (size_t)T.TI * L.nk() * 4 +
+  const size_t lds = sizeof(EdgeRec) * T.PT * T.TI + (size_t)T.PT * T.TI * J * 4 + (size_t)T.TI * (L.nk() + 1) * 4 +
                      (size_t)L.C1() * 256 * 4;
-  bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, part, N, L.I, L.O, L.G, L.act, chunk, T);
+  bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, L.ginfo, part, N, L.I, L.O, L.G, L.act, chunk,
+                                                        T);
 }
 
 template <int D, int D2>

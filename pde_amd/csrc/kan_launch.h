@@ -13,6 +13,7 @@ struct LayerView {
   const float* base_w;     // [O][I]
   const float* spline_w;   // [O][I][G+3]
   const float* scaler;     // [O][I] or nullptr
+  const float* ginfo;      // [I]: 1/h of a feature whose knots are equally spaced, else 0; nullptr = unknown
   int C() const { return G + 3; }
   int C1() const { return G + 4; }
   int nk() const { return G + 7; }
@@ -20,6 +21,7 @@ struct LayerView {
 };
 
 // kan_kernels.hip
+void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st);
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st);
 bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
                       int I, hipStream_t st);

@@ -125,6 +125,68 @@ KAN_HD void eval_basis(const KnotPtr g, int nk, float x, Basis& out) {
   }
 }
 
+// Same outputs for a feature whose knots are equally spaced (the grid every
+// KANLinear is built with, kan.py:27-35, until update_grid moves it): with
+// t = (x - g_s) / h in [0,1) the four live cubic bases are fixed polynomials,
+//   N0 = (1-t)^3/6, N1 = (3t^3-6t^2+4)/6, N2 = (-3t^3+3t^2+3t+1)/6, N3 = t^3/6,
+// and each derivative order brings one factor 1/h.  No reciprocals, 2 knot reads.
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis_uniform(const KnotPtr g, int nk, float inv_h, float x, Basis& out) {
+  const float g0 = g[0];
+  float u = (x - g0) * inv_h;
+  int s = (u > 0.0f) ? (int)u : 0;
+  if (s > nk - 2) s = nk - 2;
+  while (s > 0 && x < g[s]) --s;            // rounding at a knot: at most one step
+  while (s < nk - 2 && x >= g[s + 1]) ++s;
+  out.c0 = s - kOrder;
+  out.inside = (x >= g0) && (x < g[nk - 1]);
+  const float m = out.inside ? 1.0f : 0.0f;
+  const float t = out.inside ? (x - g[s]) * inv_h : 0.0f;
+  const float t2 = t * t, t3 = t2 * t, q = 1.0f - t;
+  const float sixth = 1.0f / 6.0f;
+  out.b[0] = m * (q * q * q * sixth);
+  out.b[1] = m * ((3.0f * t3 - 6.0f * t2 + 4.0f) * sixth);
+  out.b[2] = m * ((-3.0f * t3 + 3.0f * t2 + 3.0f * t + 1.0f) * sixth);
+  out.b[3] = m * (t3 * sixth);
+  const float s1 = m * inv_h;
+  out.d1[0] = s1 * (-0.5f * q * q);
+  out.d1[1] = s1 * (1.5f * t2 - 2.0f * t);
+  out.d1[2] = s1 * (-1.5f * t2 + t + 0.5f);
+  out.d1[3] = s1 * (0.5f * t2);
+  const float s2 = s1 * inv_h;
+  out.d2[0] = s2 * q;
+  out.d2[1] = s2 * (3.0f * t - 2.0f);
+  out.d2[2] = s2 * (1.0f - 3.0f * t);
+  out.d2[3] = s2 * t;
+  if (kNeedD3) {
+    const float s3 = s2 * inv_h;
+    out.d3[0] = -s3; out.d3[1] = 3.0f * s3; out.d3[2] = -3.0f * s3; out.d3[3] = s3;
+  } else {
+    out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
+  }
+}
+
+// 1/h when the nk knots are equally spaced to within 1e-6*h, else 0.  The default
+// grids of grid_size 5 and 10 are (fp32 rounding of the knot values moves their
+// spacing by <= 4.5e-7*h); at grid_size 20 the rounding is 1.5e-6*h, which would
+// cost ~8e-6 in the third derivative, so those grids keep the general path.
+template <typename KnotPtr>
+KAN_HD float equal_spacing_inv_h(const KnotPtr g, int nk) {
+  const float h = (g[nk - 1] - g[0]) / (float)(nk - 1);
+  float dev = 0.0f;
+  for (int k = 0; k + 1 < nk; ++k) dev = fmaxf(dev, fabsf((g[k + 1] - g[k]) - h));
+  return (h > 0.0f && dev <= 1e-6f * h) ? 1.0f / h : 0.0f;
+}
+
+// Knot rows staged in LDS carry one extra float after the nk knots: 1/h when the
+// feature's knots are equally spaced, 0 otherwise (see grid_info_kernel).
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis_row(const KnotPtr row, int nk, float x, Basis& out) {
+  const float inv_h = row[nk];
+  if (inv_h > 0.0f) eval_basis_uniform<kNeedD3>(row, nk, inv_h, x, out);
+  else eval_basis<kNeedD3>(row, nk, x, out);
+}
+
 // Base activation and its first three derivatives (kan.py:158; the scripts
 // pass nn.Identity, the module default is SiLU).
 struct Act { float f0, f1, f2, f3; };

@@ -28,14 +28,19 @@ namespace pdekan {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKnotPad = 28;   // >= G+7 for G <= 21
+constexpr int kKnotPad = 28;   // >= G+7 knots + 1 slot for the feature's 1/h, G <= 20
+
+// k-th float of the staged knot row of a feature: a knot, or (k == nk) its 1/h / 0
+__device__ __forceinline__ float knot_row_value(const float* grid, const float* ginfo, int feature, int k, int nk) {
+  return (k < nk) ? grid[(size_t)feature * nk + k] : (ginfo ? ginfo[feature] : 0.0f);
+}
 
 // ---- expanded basis jets of one (point, feature) -------------------------
 // e[m] (m<4): jets of spline column c0+m ; e[4]: jets of the base-activation column
 __device__ __forceinline__ void expand_jets(const float* knots, int nk, int act, float4 jet,
                                             float4 (&e)[5], int& c0) {
   Basis bs;
-  eval_basis<false>(knots, nk, jet.x, bs);
+  eval_basis_row<false>(knots, nk, jet.x, bs);
   const Act av = eval_act(act, jet.x);
   const float s2 = jet.y * jet.y;
 #pragma unroll
@@ -110,13 +115,15 @@ __device__ __forceinline__ void store_rows16(const f32x4 (&wreg)[WV], float* dst
 // ==========================================================================
 template <int C1, int KI>
 __global__ void __launch_bounds__(256, 2)
-fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ wt,
+fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                const float* __restrict__ wt,
                 float4* __restrict__ y, int64_t N, int I, int O, int act) {
   constexpr int KK = KI * C1;
   static_assert(KK % 2 == 0, "k-step of 2");
   constexpr int nk = C1 + 3;               // G + 7
   constexpr int WV = (KK * 16 + 255) / 256;
-  static_assert(KI * nk <= 256, "one knot per thread");
+  constexpr int kr = nk + 1;               // knots + 1/h
+  static_assert(KI * kr <= 256, "one knot-row float per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sW = reinterpret_cast<float*>(smem);            // [KK][64]
   float* sA = sW + KK * 64;                              // [4][KK][64]
@@ -131,21 +138,21 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
   const int h = lane >> 5, r = lane & 31;
   int64_t pj = P0 + p_local;
   if (pj > N - 1) pj = N - 1;
-  const int kf = tid / nk, kk_ = tid - kf * nk;          // knot slot of this thread
+  const int kf = tid / kr, kk_ = tid - kf * kr;          // knot-row slot of this thread
 
   f32x4 wreg[WV];                                        // native vectors: HIP float4 copies pin arrays in scratch
   float kreg = 0.f;
   float4 jet = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* wsrc = wt + o0;                           // slab i0 starts at row i0*C1
-  const bool knot_thread = tid < KI * nk;
+  const bool knot_thread = tid < KI * kr;
   const bool gen_lane = f_local < KI;
 
-  if (knot_thread) sK[kf * kKnotPad + kk_] = grid[(size_t)kf * nk + kk_];
+  if (knot_thread) sK[kf * kKnotPad + kk_] = knot_row_value(grid, ginfo, kf, kk_, nk);
   if (gen_lane) zero_strip<C1>(tileA, 64, f_local, p_local);
   int prev_c0 = -100;
   fetch_rows16<WV, KK * 16>(wreg, wsrc, O, tid);
   if (gen_lane) jet = a[pj * I + f_local];
-  if (KI < I && knot_thread) kreg = grid[(size_t)(KI + kf) * nk + kk_];
+  if (KI < I && knot_thread) kreg = knot_row_value(grid, ginfo, KI + kf, kk_, nk);
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
@@ -164,7 +171,7 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
     if (more) {
       fetch_rows16<WV, KK * 16>(wreg, wsrc + (size_t)(i0 + KI) * C1 * O, O, tid);
       if (gen_lane) jet = a[pj * I + i0 + KI + f_local];
-      if (i0 + 2 * KI < I && knot_thread) kreg = grid[(size_t)(i0 + 2 * KI + kf) * nk + kk_];
+      if (i0 + 2 * KI < I && knot_thread) kreg = knot_row_value(grid, ginfo, i0 + 2 * KI + kf, kk_, nk);
     }
     __syncthreads();
     // operands are read from LDS one k-step ahead of the MFMAs that consume them
@@ -212,7 +219,7 @@ fwd_mfma_kernel(const float4* __restrict__ a, const float* __restrict__ grid, co
 template <int C1, int KIW, int PB>
 __global__ void __launch_bounds__(256, 2)
 bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
-                       const float* __restrict__ grid, float* __restrict__ part,
+                       const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
                        int64_t N, int I, int O, int act, int64_t chunk_pts) {
   constexpr int COLS = KIW * C1;
   static_assert(COLS % 16 == 0, "16-wide column tiles");
@@ -236,9 +243,9 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
   float* tileE = sE + wave * COLS * RS;
   const int q = lane >> 4, l15 = lane & 15;
 
-  for (int idx = tid; idx < 4 * KIW * nk; idx += 256) {
-    const int f = idx / nk, k = idx - f * nk;
-    sK[f * kKnotPad + k] = grid[(size_t)(blockIdx.x * 4 * KIW + f) * nk + k];
+  for (int idx = tid; idx < 4 * KIW * (nk + 1); idx += 256) {
+    const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, blockIdx.x * 4 * KIW + f, k, nk);
   }
   if (gen_lane) zero_strip<C1>(tileE, RS, f_local, p_local);
   int prev_c0 = -100;
@@ -336,7 +343,7 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 template <int C1, int KIS, int OT>
 __global__ void __launch_bounds__(256, (OT > 1 ? 1 : 2))   // wide layers keep 32*OT gY registers per lane
 bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
-                      const float* __restrict__ grid, const float* __restrict__ wp,
+                      const float* __restrict__ grid, const float* __restrict__ ginfo, const float* __restrict__ wp,
                       float4* __restrict__ ga, int64_t N, int I, int O, int act) {
   constexpr int C = C1 - 1;
   constexpr int COLS = KIS * C1;
@@ -352,7 +359,8 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
                                                 : (W_FLOATS > T_FLOATS ? W_FLOATS : T_FLOATS));
   constexpr int WV = (64 * (COLS / 4) + 255) / 256;       // float4 of W tile per thread
   constexpr int NP = (8 * KIS + 63) / 64;                 // (point, feature) pairs per lane
-  static_assert(KIS * nk <= 2 * 256, "knots: at most two per thread");
+  constexpr int kr = nk + 1;                              // knots + 1/h
+  static_assert(KIS * kr <= 2 * 256, "knot rows: at most two floats per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sU = reinterpret_cast<float*>(smem);             // union: gY staging / W tile / gE tiles
   float* sK = sU + U_FLOATS;                              // [KIS][kKnotPad]
@@ -389,7 +397,7 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
   f32x4 wreg[WV];                                         // native vectors: HIP float4 copies pin arrays in scratch
   float kreg0 = 0.f, kreg1 = 0.f;
   f32x4 jete[NP];
-  const int k0f = tid / nk, k0k = tid % nk, k1f = (tid + 256) / nk, k1k = (tid + 256) % nk;
+  const int k0f = tid / kr, k0k = tid % kr, k1f = (tid + 256) / kr, k1k = (tid + 256) % kr;
 #define PDEKAN_FETCH_W(I0, OC)                                                                     \
   _Pragma("unroll") for (int v = 0; v < WV; ++v) {                                                 \
     int idx = tid + v * 256;                                                                       \
@@ -399,8 +407,8 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
   }
 #define PDEKAN_FETCH_KNOTS(I0)                                                                     \
   {                                                                                                \
-    if (tid < KIS * nk) kreg0 = grid[(size_t)((I0) + k0f) * nk + k0k];                             \
-    if (tid + 256 < KIS * nk) kreg1 = grid[(size_t)((I0) + k1f) * nk + k1k];                       \
+    if (tid < KIS * kr) kreg0 = knot_row_value(grid, ginfo, (I0) + k0f, k0k, nk);                  \
+    if (tid + 256 < KIS * kr) kreg1 = knot_row_value(grid, ginfo, (I0) + k1f, k1k, nk);            \
   }
   PDEKAN_FETCH_W(0, 0)
   PDEKAN_FETCH_KNOTS(0)
@@ -422,8 +430,8 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
       }                                                                                            \
     }                                                                                              \
     if ((OC) == 0) {                                                                               \
-      if (tid < KIS * nk) sK[k0f * kKnotPad + k0k] = kreg0;                                        \
-      if (tid + 256 < KIS * nk) sK[k1f * kKnotPad + k1k] = kreg1;                                  \
+      if (tid < KIS * kr) sK[k0f * kKnotPad + k0k] = kreg0;                                        \
+      if (tid + 256 < KIS * kr) sK[k1f * kKnotPad + k1k] = kreg1;                                  \
     }                                                                                              \
     /* next W tile: next output chunk of this slab, or the first of the next slab */               \
     if ((OC) + 1 < OT) {                                                                           \
@@ -477,7 +485,7 @@ bwd_input_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ g
       if (f_local < KIS && p < N) {
         const float4 jet = make_float4(jete[v][0], jete[v][1], jete[v][2], jete[v][3]);
         Basis bs;
-        eval_basis<true>(sK + f_local * kKnotPad, nk, jet.x, bs);
+        eval_basis_row<true>(sK + f_local * kKnotPad, nk, jet.x, bs);
         const Act av = eval_act(act, jet.x);
         const float4* col = sS + p_local * COLS + f_local * C1;
         const float s2 = jet.y * jet.y;
@@ -556,7 +564,8 @@ static void fwd_launch(const LayerView& L, const float* a, const float* wt, floa
   auto k = fwd_mfma_kernel<C1, KI>;
   allow_big_lds(k, lds);
   dim3 g((unsigned)((N + 63) / 64), L.O / 64);
-  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), L.grid, wt, reinterpret_cast<float4*>(y), N, L.I, L.O, L.act);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), L.grid, L.ginfo, wt, reinterpret_cast<float4*>(y), N, L.I,
+                         L.O, L.act);
 }
 
 void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
@@ -575,8 +584,8 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
   allow_big_lds(k, lds);
   dim3 g(L.I / (4 * KIW), L.O / 64, nchunks);
-  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy), L.grid, part, N, L.I,
-                         L.O, L.act, chunk);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part,
+                         N, L.I, L.O, L.act, chunk);
 }
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
@@ -597,7 +606,7 @@ static void bwi_launch(const LayerView& L, const float* a, const float* gy, cons
   auto k = bwd_input_mfma_kernel<C1, KIS, OT>;
   allow_big_lds(k, lds);
   k<<<(unsigned)((N + 31) / 32), 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy),
-                                                 L.grid, wp, reinterpret_cast<float4*>(ga), N, L.I, L.O, L.act);
+                                                 L.grid, L.ginfo, wp, reinterpret_cast<float4*>(ga), N, L.I, L.O, L.act);
 }
 
 template <int C1, int KIS>

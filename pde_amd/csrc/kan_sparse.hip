@@ -63,7 +63,7 @@ struct Live {
 template <bool kNeedD3>
 __device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_kind, float x) {
   Basis bs;
-  eval_basis<kNeedD3>(knots, nk, x, bs);
+  eval_basis_row<kNeedD3>(knots, nk, x, bs);
   Live L;
 #pragma unroll
   for (int m = 0; m < 4; ++m) { L.b[m] = bs.b[m]; L.d1[m] = bs.d1[m]; L.d2[m] = bs.d2[m]; L.d3[m] = bs.d3[m]; }
@@ -105,7 +105,8 @@ __device__ __forceinline__ void table_store(const TableRegs<O>& r, float* sT, fl
 // ==========================================================================
 template <int O>
 __global__ void __launch_bounds__(256, 2)
-fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ win,
+fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                  const float* __restrict__ win,
                   const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act) {
   constexpr int OG = O / 32;              // output groups = lanes per point
   constexpr int PW = 64 / OG;             // points per wave
@@ -121,7 +122,10 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   const bool live_pt = p < N;
   if (!live_pt) p = N - 1;
 
-  for (int t = tid; t < I * nk; t += 256) sK[(t / nk) * kKnotPadS + t % nk] = grid[t];
+  for (int t = tid; t < I * (nk + 1); t += 256) {        // knot rows + the feature's 1/h (0 = not equally spaced)
+    const int f = t / (nk + 1), k = t - f * (nk + 1);
+    sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
+  }
   TableRegs<O> tr;
   table_fetch<O>(tr, win, wbt, 0, tid);
   table_store<O>(tr, sT, sB, tid);
@@ -191,7 +195,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
 template <int O>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
-                        const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
+                        const float* __restrict__ ginfo, const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
                         int64_t N, int I, int G, int act) {
   constexpr int OG = O / 32;
   constexpr int PW = 64 / OG;
@@ -207,7 +211,10 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   const bool live_pt = p < N;
   if (!live_pt) p = N - 1;
 
-  for (int t = tid; t < I * nk; t += 256) sK[(t / nk) * kKnotPadS + t % nk] = grid[t];
+  for (int t = tid; t < I * (nk + 1); t += 256) {        // knot rows + the feature's 1/h (0 = not equally spaced)
+    const int f = t / (nk + 1), k = t - f * (nk + 1);
+    sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
+  }
   TableRegs<O> tr;
   table_fetch<O>(tr, win, wbt, 0, tid);
   table_store<O>(tr, sT, sB, tid);
@@ -320,13 +327,13 @@ void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, flo
     auto k = fwd_sparse_kernel<64>;
     const size_t lds = sparse_lds<64>(L);
     big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, win, wbt, y, N, L.I, L.G, L.act);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
   } else {
     const int pts = 4 * 16;
     auto k = fwd_sparse_kernel<128>;
     const size_t lds = sparse_lds<128>(L);
     big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, win, wbt, y, N, L.I, L.G, L.act);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
   }
 }
 
@@ -338,13 +345,13 @@ void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy
     auto k = bwd_input_sparse_kernel<64>;
     const size_t lds = sparse_lds<64>(L);
     big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, win, wbt, ga, N, L.I, L.G, L.act);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
   } else {
     const int pts = 4 * 16;
     auto k = bwd_input_sparse_kernel<128>;
     const size_t lds = sparse_lds<128>(L);
     big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, win, wbt, ga, N, L.I, L.G, L.act);
+    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
   }
 }
 

@@ -66,6 +66,7 @@ int to_view(const PdekanLayer* l, pdekan::LayerView& v) {
   if (!l->grid || !l->base_weight || !l->spline_weight) return fail(PDEKAN_ERR_ARG, "layer has NULL parameter pointers");
   v.I = l->in_features; v.O = l->out_features; v.G = l->grid_size; v.act = l->act_kind;
   v.grid = l->grid; v.base_w = l->base_weight; v.spline_w = l->spline_weight; v.scaler = l->spline_scaler;
+  v.ginfo = nullptr;
   return PDEKAN_OK;
 }
 
@@ -96,7 +97,7 @@ size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
 size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   const size_t packed = align_up(L.packed_floats() * 4) / 4;
   return 2 * packed + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4 +
-         align_up(win_floats(D, D2, L) * 4) / 4;
+         align_up(win_floats(D, D2, L) * 4) / 4 + align_up((size_t)L.I * 4) / 4;
 }
 
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
@@ -187,7 +188,7 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
 }
 
 struct ModelWs {
-  std::vector<float*> wp, wt, win, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
+  std::vector<float*> wp, wt, win, ginfo, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
   float* g[2];
   float* part;
   float* loss_part;
@@ -203,10 +204,11 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     total += align_up(floats * 4);
     return ws ? c.take(floats) : nullptr;
   };
-  W.wp.resize(nl); W.wt.resize(nl); W.win.resize(nl); W.act.resize(nl + 1);
+  W.wp.resize(nl); W.wt.resize(nl); W.win.resize(nl); W.ginfo.resize(nl); W.act.resize(nl + 1);
   for (size_t l = 0; l < nl; ++l) {
     W.wp[l] = take(P.L[l].packed_floats());
     W.wt[l] = take(P.L[l].packed_floats());
+    W.ginfo[l] = take(P.L[l].I);
     const size_t wf = win_floats(P.D, P.D2, P.L[l]);
     W.win[l] = wf ? take(wf) : nullptr;
     if (!ws && wf) W.win[l] = reinterpret_cast<float*>(1);   // sizing pass: only the total matters
@@ -259,8 +261,11 @@ int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_
   float* wt = c.take(L.packed_floats());
   const size_t wf = win_floats(n_dir, n_second, L);
   float* win = wf ? c.take(wf) : nullptr;
+  float* ginfo = c.take(L.I);
   if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
+  pdekan::launch_grid_info(L, ginfo, st);
+  L.ginfo = ginfo;
   pdekan::launch_pack_weights(L, wp, wt, st);
   if (win) pdekan::launch_pack_window(L, wp, win, st);
   return run_forward(n_dir, n_second, L, x_jet, wt, win, y_jet, n, st);
@@ -281,8 +286,11 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   float* part = c.take((size_t)(weight_chunks(n_dir, n_second, L, n) + 1) * L.packed_floats());
   const size_t wf = (gx_jet != nullptr) ? win_floats(n_dir, n_second, L) : 0;
   float* win = wf ? c.take(wf) : nullptr;
+  float* ginfo = c.take(L.I);
   if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
+  pdekan::launch_grid_info(L, ginfo, st);
+  L.ginfo = ginfo;
   pdekan::launch_pack_weights(L, wp, wt, st);
   if (win) pdekan::launch_pack_window(L, wp, win, st);
   return run_backward(n_dir, n_second, L, x_jet, gy_jet, wp, win, gx_jet, part, grads, accumulate, n, st);
@@ -312,6 +320,8 @@ int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const 
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
   for (int l = 0; l < nl; ++l) {
+    pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
+    P.L[l].ginfo = W.ginfo[l];
     pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
     if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
   }
@@ -349,6 +359,8 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   {
     ProfScope ps(st, "pack_weights", 0);
     for (int l = 0; l < nl; ++l) {
+      pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
+      P.L[l].ginfo = W.ginfo[l];
       pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
       if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
     }

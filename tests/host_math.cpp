@@ -93,6 +93,19 @@ void hm_eval_basis(const float* knots, int nk, float x, float* out16, int* c0, i
   *c0 = bs.c0; *inside = bs.inside;
 }
 
+// knots followed by the 1/h slot, as the kernels stage them; uniform != 0 takes the equal-spacing path
+void hm_eval_basis_row(const float* knots, int nk, int uniform, float x, float* out16, int* c0, int* inside) {
+  std::vector<float> row(knots, knots + nk);
+  const float h = (knots[nk - 1] - knots[0]) / (float)(nk - 1);
+  row.push_back(uniform == 1 ? 1.0f / h : uniform == 2 ? equal_spacing_inv_h(knots, nk) : 0.0f);
+  Basis bs;
+  eval_basis_row<true>(row.data(), nk, x, bs);
+  for (int m = 0; m < 4; ++m) { out16[m] = bs.b[m]; out16[4 + m] = bs.d1[m]; out16[8 + m] = bs.d2[m]; out16[12 + m] = bs.d3[m]; }
+  *c0 = bs.c0; *inside = bs.inside;
+}
+
+float hm_equal_spacing_inv_h(const float* knots, int nk) { return equal_spacing_inv_h(knots, nk); }
+
 void hm_eval_act(int kind, float x, float* out4) {
   const Act a = eval_act(kind, x);
   out4[0] = a.f0; out4[1] = a.f1; out4[2] = a.f2; out4[3] = a.f3;

@@ -295,3 +295,32 @@ def test_hidden_layer_paths_match_oracle(widths, G, N, disable, monkeypatch):
     jet = m.forward_jet(x.cuda())
     assert max_rel(jet[:, 0, 0].cpu(), ref["v"]) <= TOL
     assert max_rel(jet[:, 0, 3].cpu(), ref["second"][:, 0]) <= TOL
+
+
+def test_moved_grid_takes_the_general_basis_path():
+    """After update_grid the knots are no longer equally spaced: the kernels must
+    fall back from the polynomial fast path to the local de Boor triangle (hidden
+    64x64 layer: sparse forward/input-gradient kernels and the MFMA weight-gradient kernel)."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model([2, 64, 64, 1], 10, 77).cuda()
+    gen = torch.Generator().manual_seed(78)
+    samples = (torch.rand(512, 2, generator=gen) * 1.2 - 0.1).cuda()
+    with torch.no_grad():
+        m(samples, update_grid=True)              # kan.py:274-279 with update_grid=True
+    g1 = m.layers[1].grid[0]
+    steps = g1[1:] - g1[:-1]
+    assert (steps.max() - steps.min()).item() > 1e-3      # really non-uniform now
+    x = torch.rand(300, 2, generator=gen)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = O.pinn_step(x.double(), O.layers_from_state_dict(sd, dtype=torch.float64), "silu")
+    step = BlackScholesStep(m)
+    res = torch.empty(300, device="cuda")
+    loss = step(x.cuda(), residual_out=res).item()
+    assert max_rel(res.cpu(), ref["res"]) <= TOL
+    assert abs(loss - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    off = 0
+    for l in range(3):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            n = ref["grads"][l][k].numel()
+            assert max_rel(step.flat_grad[off:off + n].cpu(), ref["grads"][l][k].flatten()) <= TOL, (l, k)
+            off += n

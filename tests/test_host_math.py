@@ -72,6 +72,47 @@ def test_local_basis_matches_dense_cox_de_boor(hm, G):
         assert inside == int(knots[0] <= x < knots[-1])
 
 
+def test_equal_spacing_rule(hm):
+    """Which grids take the polynomial fast path: the default grids of size 5 and
+    10 do, size 20 (knot rounding ~2.5e-6*h) and any moved grid do not."""
+    hm.hm_equal_spacing_inv_h.restype = ctypes.c_float
+    for G, expect in ((5, True), (10, True), (20, False)):
+        knots = O.uniform_grid(1, G)[0].numpy().copy()
+        inv_h = hm.hm_equal_spacing_inv_h(fptr(knots), len(knots))
+        assert (inv_h > 0) == expect, (G, inv_h)
+        if expect:
+            assert abs(inv_h - G / 2.0) < 1e-4
+    moved = O.uniform_grid(1, 10)[0].numpy().copy()
+    moved[7] += 1e-4
+    assert hm.hm_equal_spacing_inv_h(fptr(moved), len(moved)) == 0.0
+
+
+@pytest.mark.parametrize("G", [5, 10])
+def test_equal_spacing_fast_path_matches_dense_cox_de_boor(hm, G):
+    """The polynomial fast path the kernels take on the reference's default grid."""
+    knots = O.uniform_grid(1, G)[0].numpy().copy()
+    C = G + 3
+    h = 2.0 / G
+    xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 401),
+                         knots.astype(np.float64), [-7.0, 9.0]]).astype(np.float32)
+    ref = dense_reference(knots, xs, C)
+    scale = np.array([1.0, 1 / h, 1 / h ** 2, 1 / h ** 3])[:, None]
+    out = np.zeros(16, np.float32)
+    c0, inside = ctypes.c_int(), ctypes.c_int()
+    worst = 0.0
+    for n, x in enumerate(xs):
+        hm.hm_eval_basis_row(fptr(knots), len(knots), 1, ctypes.c_float(x), fptr(out), ctypes.byref(c0),
+                             ctypes.byref(inside))
+        dense = np.zeros((4, C))
+        for m in range(4):
+            c = c0.value + m
+            if 0 <= c < C:
+                dense[:, c] = out[m::4]
+        worst = max(worst, np.abs((dense - ref[:, n]) / scale).max())
+        assert inside.value == int(knots[0] <= x < knots[-1])
+    assert worst < 5e-6, worst
+
+
 def test_local_basis_nonuniform_knots(hm):
     rng = np.random.default_rng(0)
     knots = np.sort(rng.uniform(-2, 2, 12)).astype(np.float32)
