@@ -100,6 +100,56 @@ __device__ __forceinline__ void table_store(const TableRegs<O>& r, float* sT, fl
   if (tid < O) sB[tid] = r.base;
 }
 
+// --------------------------------------------------------------------------
+// Input jets a[N][I][4] are consumed one feature at a time by lanes that each own
+// a point: read directly that is a 16-byte load per lane at a 16*I-byte stride.
+// Instead a wave stages kFS = 4 features of its PW points at a time: 4 lanes
+// fetch the 64 contiguous bytes of one point, the wave parks them in LDS
+// ([point][feature][4]) and every lane then picks its point's jet from there.
+// --------------------------------------------------------------------------
+constexpr int kFS = 4;
+
+// The copy is an LDS-DMA load (no VGPR destination): lane l of chunk k lands at
+// base + (64*k + l)*16 bytes, which is exactly [point][feature][4] for point =
+// (64*k + l)/4.  The next __syncthreads() retires it.
+//
+// WaveRows holds the wave's view of a [N][I][4] tensor: a wave-uniform base and
+// the per-lane element offsets of its chunks (rows past the end of the batch are
+// clamped onto the last live row for loads and masked for stores).
+template <int PW>
+struct WaveRows {
+  static constexpr int NV = (PW * kFS) / 64;
+  int64_t base;      // first point of the wave (clamped into the batch), wave-uniform
+  int nlive;         // live points of the wave, wave-uniform
+  int off[NV];       // (row * I + feature-in-stage) * 4
+  int row[NV];
+};
+
+template <int PW>
+__device__ __forceinline__ WaveRows<PW> wave_rows(int64_t P0, int64_t N, int I, int lane) {
+  WaveRows<PW> r;
+  int64_t left = N - P0;
+  r.nlive = left <= 0 ? 0 : (left < PW ? (int)left : PW);
+  r.base = r.nlive > 0 ? P0 : N - 1;
+#pragma unroll
+  for (int k = 0; k < WaveRows<PW>::NV; ++k) {
+    const int c = lane + 64 * k;
+    r.row[k] = c / kFS;
+    const int rc = r.row[k] < r.nlive ? r.row[k] : (r.nlive > 0 ? r.nlive - 1 : 0);
+    r.off[k] = (rc * I + (c % kFS)) * 4;
+  }
+  return r;
+}
+
+template <int PW>
+__device__ __forceinline__ void jets_stage(float* sJ, const float* a, const WaveRows<PW>& r, int I, int i0) {
+  const float* src = a + (r.base * I + i0) * 4;
+#pragma unroll
+  for (int k = 0; k < WaveRows<PW>::NV; ++k)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r.off[k]),
+                                     (__attribute__((address_space(3))) void*)(sJ + 64 * k * 4), 16, 0, 0);
+}
+
 // ==========================================================================
 // forward
 // ==========================================================================
@@ -114,13 +164,17 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);            // [2][O*64]
   float* sB = sT + 2 * O * 64;                           // [2][O]
-  float* sK = sB + 2 * O;                                // [I][kKnotPadS]
+  float* sJ = sB + 2 * O;                                // [4 waves][2][PW][kFS][4] staged input jets
+  float* sK = sJ + 4 * 2 * PW * kFS * 4;                 // [I][kKnotPadS]
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = lane / PW, pl = lane % PW;
-  int64_t p = ((int64_t)blockIdx.x * 4 + wave) * PW + pl;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * PW;     // first point of the wave
+  int64_t p = P0 + pl;
   const bool live_pt = p < N;
   if (!live_pt) p = N - 1;
+  float* sJw = sJ + wave * 2 * PW * kFS * 4;
+  const WaveRows<PW> wr = wave_rows<PW>(P0, N, I, lane);
 
   for (int t = tid; t < I * (nk + 1); t += 256) {        // knot rows + the feature's 1/h (0 = not equally spaced)
     const int f = t / (nk + 1), k = t - f * (nk + 1);
@@ -130,21 +184,22 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   table_fetch<O>(tr, win, wbt, 0, tid);
   table_store<O>(tr, sT, sB, tid);
   if (I > 1) table_fetch<O>(tr, win, wbt, 1, tid);
+  jets_stage<PW>(sJw, a, wr, I, 0);
 
   f32x4 acc[32];
 #pragma unroll
   for (int o = 0; o < 32; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 jet = *reinterpret_cast<const f32x4*>(a + (p * I) * 4);
 
   for (int i = 0; i < I; ++i) {
-    __syncthreads();                       // table i visible; buffer (i+1)&1 free
+    __syncthreads();                       // table i and staged jets visible; buffer (i+1)&1 free
     const int buf = i & 1;
     if (i + 1 < I) {
       table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
       if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
     }
-    const f32x4 cur = jet;
-    if (i + 1 < I) jet = *reinterpret_cast<const f32x4*>(a + (p * I + i + 1) * 4);
+    if ((i % kFS) == 0 && i + kFS < I)     // features i+4..i+7 into the other staging buffer
+      jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
+    const f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (((i / kFS) & 1) * PW * kFS + pl * kFS + (i % kFS)) * 4);
     const Live L = eval_live<false>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float s2 = cur[1] * cur[1];
     // expanded jets of the 4 live splines and of the base column
@@ -203,13 +258,28 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);
   float* sB = sT + 2 * O * 64;
-  float* sK = sB + 2 * O;
+  float* sJ = sB + 2 * O;                                // [4 waves][2][PW][kFS][4] staged input jets
+  float* sO = sJ + 4 * 2 * PW * kFS * 4;                 // [4 waves][PW][kFS][4] staged output gradients
+  float* sK = sO + 4 * PW * kFS * 4;
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = lane / PW, pl = lane % PW;
-  int64_t p = ((int64_t)blockIdx.x * 4 + wave) * PW + pl;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * PW;
+  int64_t p = P0 + pl;
   const bool live_pt = p < N;
   if (!live_pt) p = N - 1;
+  float* sJw = sJ + wave * 2 * PW * kFS * 4;
+  float* sOw = sO + wave * PW * kFS * 4;
+  // write the kFS gradients parked for features i0..i0+3: 4 lanes store the 64 contiguous bytes of a point
+  const WaveRows<PW> wr = wave_rows<PW>(P0, N, I, lane);
+  auto flush_out = [&](int i0) {
+    float* dst = ga + (wr.base * I + i0) * 4;
+#pragma unroll
+    for (int k = 0; k < WaveRows<PW>::NV; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sOw + (lane + 64 * k) * 4);
+      if (wr.row[k] < wr.nlive) *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
+    }
+  };
 
   for (int t = tid; t < I * (nk + 1); t += 256) {        // knot rows + the feature's 1/h (0 = not equally spaced)
     const int f = t / (nk + 1), k = t - f * (nk + 1);
@@ -227,7 +297,7 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
 #pragma unroll
     for (int o = 0; o < 32; ++o) gyr[o] = src[o];
   }
-  f32x4 jet = *reinterpret_cast<const f32x4*>(a + (p * I) * 4);
+  jets_stage<PW>(sJw, a, wr, I, 0);
 
   for (int i = 0; i < I; ++i) {
     __syncthreads();
@@ -236,8 +306,11 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
       if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
     }
-    const f32x4 cur = jet;
-    if (i + 1 < I) jet = *reinterpret_cast<const f32x4*>(a + (p * I + i + 1) * 4);
+    if ((i % kFS) == 0) {
+      if (i > 0) flush_out(i - kFS);       // gradients of the previous 4 features, parked before the barrier
+      if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
+    }
+    const f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (((i / kFS) & 1) * PW * kFS + pl * kFS + (i % kFS)) * 4);
     const Live L = eval_live<true>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
     const float* bb = sB + buf * O + g * 32;
@@ -284,8 +357,10 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
 #pragma unroll
       for (int j = 0; j < 4; ++j) out[j] += __shfl_xor(out[j], off);
     }
-    if (g == 0 && live_pt) *reinterpret_cast<f32x4*>(ga + (p * I + i) * 4) = out;
+    if (g == 0) *reinterpret_cast<f32x4*>(sOw + (pl * kFS + (i % kFS)) * 4) = out;
   }
+  __syncthreads();
+  flush_out(I - kFS);
 }
 
 // ==========================================================================
@@ -297,7 +372,7 @@ bool sparse_eligible(int D, int D2, const LayerView& L) {
   if (off && off[0] == '1') return false;
   if (L.G + 6 > kSlots) return false;
   if (L.O != 64 && L.O != 128) return false;
-  if (L.I < 8 || L.I > 256) return false;
+  if (L.I < 8 || L.I > 256 || L.I % kFS != 0) return false;
   return true;
 }
 
@@ -311,8 +386,10 @@ void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStre
 }
 
 template <int O>
-static size_t sparse_lds(const LayerView& L) {
-  return (size_t)(2 * O * 64 + 2 * O + L.I * kKnotPadS) * 4;
+static size_t sparse_lds(const LayerView& L, bool with_out_stage) {
+  constexpr int PW = 64 / (O / 32);
+  return (size_t)(2 * O * 64 + 2 * O + 4 * 2 * PW * kFS * 4 + (with_out_stage ? 4 * PW * kFS * 4 : 0) +
+                  L.I * kKnotPadS) * 4;
 }
 
 template <typename Kern>
@@ -325,13 +402,13 @@ void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, flo
   if (L.O == 64) {
     const int pts = 4 * 32;
     auto k = fwd_sparse_kernel<64>;
-    const size_t lds = sparse_lds<64>(L);
+    const size_t lds = sparse_lds<64>(L, false);
     big_lds(k, lds);
     k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
   } else {
     const int pts = 4 * 16;
     auto k = fwd_sparse_kernel<128>;
-    const size_t lds = sparse_lds<128>(L);
+    const size_t lds = sparse_lds<128>(L, false);
     big_lds(k, lds);
     k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
   }
@@ -343,13 +420,13 @@ void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy
   if (L.O == 64) {
     const int pts = 4 * 32;
     auto k = bwd_input_sparse_kernel<64>;
-    const size_t lds = sparse_lds<64>(L);
+    const size_t lds = sparse_lds<64>(L, true);
     big_lds(k, lds);
     k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
   } else {
     const int pts = 4 * 16;
     auto k = bwd_input_sparse_kernel<128>;
-    const size_t lds = sparse_lds<128>(L);
+    const size_t lds = sparse_lds<128>(L, true);
     big_lds(k, lds);
     k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
   }
