@@ -53,6 +53,28 @@ __global__ void pack_window_kernel(const float* __restrict__ wp, float* __restri
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += v * w.x  /  acc += v * w.y  on a register pair (two fp32 lanes per instruction).
+// Written out because the compiler materialises some of these broadcasts with an
+// extra v_mov per use instead of the operand-select bits.
+__device__ __forceinline__ void pkfma_x(f32x2& acc, f32x2 v, f32x2 w) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "v"(w));
+}
+__device__ __forceinline__ void pkfma_y(f32x2& acc, f32x2 v, f32x2 w) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(v), "v"(w));
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+
+// Block barrier that also retires the LDS-DMA loads this wave has in flight: they
+// count on the vector-memory counter, which a plain __syncthreads() does not
+// always wait for, so the wait is spelled out.
+__device__ __forceinline__ void barrier_after_dma() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // Basis and activation of one (point, feature) for the sparse kernels.
 struct Live {
   f32x4 b, d1, d2, d3;   // the 4 live bases and derivatives
@@ -75,29 +97,22 @@ __device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_ki
 }
 
 // --------------------------------------------------------------------------
-// shared staging of the per-feature tables: O*64 floats of windows + O base weights
+// Shared staging of one feature's tables (O*64 floats of windows + O base
+// weights): a straight copy, so the four waves move it with LDS-DMA loads, one
+// KiB per instruction, no registers involved.  Retired by the next barrier_after_dma().
 // --------------------------------------------------------------------------
 template <int O>
-struct TableRegs {
-  static constexpr int NV = (O * 16) / 256;     // float4 per thread: O*64 floats / (256 threads * 4)
-  f32x4 v[NV];
-  float base;
-};
-
-template <int O>
-__device__ __forceinline__ void table_fetch(TableRegs<O>& r, const float* win, const float* wbt, int i, int tid) {
-  const f32x4* src = reinterpret_cast<const f32x4*>(win + (size_t)i * O * 64);
+__device__ __forceinline__ void table_stage(float* sT, float* sB, const float* win, const float* wbt, int i, int wave,
+                                            int lane) {
+  const float* src = win + (size_t)i * O * 64 + wave * (O * 16);
+  float* dst = sT + wave * (O * 16);
 #pragma unroll
-  for (int k = 0; k < TableRegs<O>::NV; ++k) r.v[k] = src[tid + k * 256];
-  r.base = wbt[(size_t)i * O + (tid < O ? tid : 0)];
-}
-
-template <int O>
-__device__ __forceinline__ void table_store(const TableRegs<O>& r, float* sT, float* sB, int tid) {
-  f32x4* dst = reinterpret_cast<f32x4*>(sT);
-#pragma unroll
-  for (int k = 0; k < TableRegs<O>::NV; ++k) dst[tid + k * 256] = r.v[k];
-  if (tid < O) sB[tid] = r.base;
+  for (int k = 0; k < O / 16; ++k)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(dst + k * 256), 16, 0, 0);
+  if (wave < O / 64)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbt + (size_t)i * O + wave * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(sB + wave * 64), 4, 0, 0);
 }
 
 // --------------------------------------------------------------------------
@@ -111,7 +126,7 @@ constexpr int kFS = 4;
 
 // The copy is an LDS-DMA load (no VGPR destination): lane l of chunk k lands at
 // base + (64*k + l)*16 bytes, which is exactly [point][feature][4] for point =
-// (64*k + l)/4.  The next __syncthreads() retires it.
+// (64*k + l)/4.  The next barrier_after_dma() retires it.
 //
 // WaveRows holds the wave's view of a [N][I][4] tensor: a wave-uniform base and
 // the per-lane element offsets of its chunks (rows past the end of the batch are
@@ -122,7 +137,6 @@ struct WaveRows {
   int64_t base;      // first point of the wave (clamped into the batch), wave-uniform
   int nlive;         // live points of the wave, wave-uniform
   int off[NV];       // (row * I + feature-in-stage) * 4
-  int row[NV];
 };
 
 template <int PW>
@@ -134,8 +148,8 @@ __device__ __forceinline__ WaveRows<PW> wave_rows(int64_t P0, int64_t N, int I, 
 #pragma unroll
   for (int k = 0; k < WaveRows<PW>::NV; ++k) {
     const int c = lane + 64 * k;
-    r.row[k] = c / kFS;
-    const int rc = r.row[k] < r.nlive ? r.row[k] : (r.nlive > 0 ? r.nlive - 1 : 0);
+    const int row = c / kFS;
+    const int rc = row < r.nlive ? row : (r.nlive > 0 ? r.nlive - 1 : 0);
     r.off[k] = (rc * I + (c % kFS)) * 4;
   }
   return r;
@@ -180,67 +194,69 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  TableRegs<O> tr;
-  table_fetch<O>(tr, win, wbt, 0, tid);
-  table_store<O>(tr, sT, sB, tid);
-  if (I > 1) table_fetch<O>(tr, win, wbt, 1, tid);
+  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
   jets_stage<PW>(sJw, a, wr, I, 0);
 
-  f32x4 acc[32];
+  f32x2 accl[32], acch[32];               // jets (0,1) and (2,3) of the lane's 32 outputs
 #pragma unroll
-  for (int o = 0; o < 32; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int o = 0; o < 32; ++o) { accl[o] = (f32x2){0.f, 0.f}; acch[o] = (f32x2){0.f, 0.f}; }
 
   for (int i = 0; i < I; ++i) {
-    __syncthreads();                       // table i and staged jets visible; buffer (i+1)&1 free
+    barrier_after_dma();                   // table i and staged jets visible; buffer (i+1)&1 free
     const int buf = i & 1;
-    if (i + 1 < I) {
-      table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
-      if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
-    }
+    if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
     if ((i % kFS) == 0 && i + kFS < I)     // features i+4..i+7 into the other staging buffer
       jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
     const f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (((i / kFS) & 1) * PW * kFS + pl * kFS + (i % kFS)) * 4);
     const Live L = eval_live<false>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float s2 = cur[1] * cur[1];
     // expanded jets of the 4 live splines and of the base column
-    f32x4 e[5];
+    f32x2 el[5], eh[5];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-      e[m] = (f32x4){L.b[m], L.d1[m] * cur[1], L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
-    e[4] = (f32x4){L.act.f0, L.act.f1 * cur[1], L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
+    for (int m = 0; m < 4; ++m) {
+      el[m] = (f32x2){L.b[m], L.d1[m] * cur[1]};
+      eh[m] = (f32x2){L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
+    }
+    el[4] = (f32x2){L.act.f0, L.act.f1 * cur[1]};
+    eh[4] = (f32x2){L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
     const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
     const float* bb = sB + buf * O + g * 32;
-    // outputs in groups of 4; the weights of group q+1 are read from LDS while group q is consumed
-    f32x4 wq[2][4], bq[2];
+    // outputs in groups of 4; the weights of group q+2 are read from LDS while group q is consumed
+    f32x4 wq[3][4], bq[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(tb + k * 64);
-    bq[0] = *reinterpret_cast<const f32x4*>(bb);
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wq[r][k] = *reinterpret_cast<const f32x4*>(tb + (r * 4 + k) * 64);
+      bq[r] = *reinterpret_cast<const f32x4*>(bb + r * 4);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int cur = q & 1, nxt = cur ^ 1;
-      if (q + 1 < 8) {
+      const int cur = q % 3, nxt = (q + 2) % 3;
+      if (q + 2 < 8) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wq[nxt][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 1) * 4 + k) * 64);
-        bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 1) * 4);
+        for (int k = 0; k < 4; ++k) wq[nxt][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 2) * 4 + k) * 64);
+        bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 2) * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 w = wq[cur][k];
-        f32x4 t = acc[q * 4 + k];         // one fma chain per accumulator: 5 x (2 packed fmas)
-        t += w[0] * e[0];
-        t += w[1] * e[1];
-        t += w[2] * e[2];
-        t += w[3] * e[3];
-        t += bq[cur][k] * e[4];
-        acc[q * 4 + k] = t;
+        const f32x2 w01 = lo2(wq[cur][k]), w23 = hi2(wq[cur][k]);
+        const f32x2 wb = (k < 2) ? lo2(bq[cur]) : hi2(bq[cur]);
+        f32x2& tl = accl[q * 4 + k];
+        f32x2& th = acch[q * 4 + k];
+        pkfma_x(tl, el[0], w01); pkfma_x(th, eh[0], w01);
+        pkfma_y(tl, el[1], w01); pkfma_y(th, eh[1], w01);
+        pkfma_x(tl, el[2], w23); pkfma_x(th, eh[2], w23);
+        pkfma_y(tl, el[3], w23); pkfma_y(th, eh[3], w23);
+        if (k & 1) { pkfma_y(tl, el[4], wb); pkfma_y(th, eh[4], wb); }
+        else       { pkfma_x(tl, el[4], wb); pkfma_x(th, eh[4], wb); }
       }
     }
   }
   if (live_pt) {
     f32x4* dst = reinterpret_cast<f32x4*>(y + (p * O + g * 32) * 4);
 #pragma unroll
-    for (int o = 0; o < 32; ++o) dst[o] = acc[o];
+    for (int o = 0; o < 32; ++o) dst[o] = (f32x4){accl[o][0], accl[o][1], acch[o][0], acch[o][1]};
   }
 }
 
@@ -277,7 +293,7 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
 #pragma unroll
     for (int k = 0; k < WaveRows<PW>::NV; ++k) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(sOw + (lane + 64 * k) * 4);
-      if (wr.row[k] < wr.nlive) *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
+      if ((lane + 64 * k) / kFS < wr.nlive) *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
     }
   };
 
@@ -285,27 +301,21 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  TableRegs<O> tr;
-  table_fetch<O>(tr, win, wbt, 0, tid);
-  table_store<O>(tr, sT, sB, tid);
-  if (I > 1) table_fetch<O>(tr, win, wbt, 1, tid);
+  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
 
   // cotangents of this lane's 32 outputs stay in registers for the whole kernel
-  f32x4 gyr[32];
+  f32x2 gyl[32], gyh[32];
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(gy + (p * O + g * 32) * 4);
 #pragma unroll
-    for (int o = 0; o < 32; ++o) gyr[o] = src[o];
+    for (int o = 0; o < 32; ++o) { const f32x4 v = src[o]; gyl[o] = lo2(v); gyh[o] = hi2(v); }
   }
   jets_stage<PW>(sJw, a, wr, I, 0);
 
   for (int i = 0; i < I; ++i) {
-    __syncthreads();
+    barrier_after_dma();
     const int buf = i & 1;
-    if (i + 1 < I) {
-      table_store<O>(tr, sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, tid);
-      if (i + 2 < I) table_fetch<O>(tr, win, wbt, i + 2, tid);
-    }
+    if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
     if ((i % kFS) == 0) {
       if (i > 0) flush_out(i - kFS);       // gradients of the previous 4 features, parked before the barrier
       if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
@@ -314,7 +324,9 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
     const Live L = eval_live<true>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
     const float* bb = sB + buf * O + g * 32;
-    f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = G0, G2 = G0, G3 = G0, Gb = G0;
+    f32x2 Gl[5], Gh[5];                    // per live column: sums over outputs of w * cotangent, jets (0,1) | (2,3)
+#pragma unroll
+    for (int m = 0; m < 5; ++m) { Gl[m] = (f32x2){0.f, 0.f}; Gh[m] = (f32x2){0.f, 0.f}; }
     f32x4 wq[2][4], bq[2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(tb + k * 64);
@@ -330,22 +342,26 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 w = wq[cw][k];
-        const f32x4 gv = gyr[q * 4 + k];
-        G0 += w[0] * gv; G1 += w[1] * gv; G2 += w[2] * gv; G3 += w[3] * gv;
-        Gb += bq[cw][k] * gv;
+        const f32x2 w01 = lo2(wq[cw][k]), w23 = hi2(wq[cw][k]);
+        const f32x2 wb = (k < 2) ? lo2(bq[cw]) : hi2(bq[cw]);
+        const f32x2 vl = gyl[q * 4 + k], vh = gyh[q * 4 + k];
+        pkfma_x(Gl[0], vl, w01); pkfma_x(Gh[0], vh, w01);
+        pkfma_y(Gl[1], vl, w01); pkfma_y(Gh[1], vh, w01);
+        pkfma_x(Gl[2], vl, w23); pkfma_x(Gh[2], vh, w23);
+        pkfma_y(Gl[3], vl, w23); pkfma_y(Gh[3], vh, w23);
+        if (k & 1) { pkfma_y(Gl[4], vl, wb); pkfma_y(Gh[4], vh, wb); }
+        else       { pkfma_x(Gl[4], vl, wb); pkfma_x(Gh[4], vh, wb); }
       }
     }
     // chain rule on this lane's partial sums (linear in G, so it commutes with the sum over groups)
     const float s2 = cur[1] * cur[1];
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 Gm[5] = {G0, G1, G2, G3, Gb};
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
       const float e1 = m < 4 ? L.d1[m & 3] : L.act.f1;
       const float e2 = m < 4 ? L.d2[m & 3] : L.act.f2;
       const float e3 = m < 4 ? L.d3[m & 3] : L.act.f3;
-      const f32x4 q = Gm[m];
+      const f32x4 q = {Gl[m][0], Gl[m][1], Gh[m][0], Gh[m][1]};
       out[0] += q[0] * e1 + (q[1] * cur[1] + q[2] * cur[2]) * e2 + q[3] * (s2 * e3 + cur[3] * e2);
       out[1] += q[1] * e1 + 2.0f * cur[1] * q[3] * e2;
       out[2] += q[2] * e1;
