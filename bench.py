@@ -92,8 +92,8 @@ def cpu_baseline(name, model_sd, widths, act, steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
