@@ -94,27 +94,30 @@ __global__ void seed_jets_kernel(const float* __restrict__ x, int64_t stride_n, 
 // thread per (point, output, i-slice) walks the inputs, gathers the 4+1 live
 // weights (coalesced over o through wt) and accumulates the output jet; the
 // NIC i-slices of one output sit in adjacent lanes and are summed by shuffles.
+// A launch covers the input features [i0, i0 + IB) (LDS holds that window only);
+// wide layers are walked window by window, later windows adding into y.
 // --------------------------------------------------------------------------
 template <int D, int D2>
 __global__ void __launch_bounds__(256)
 fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                    const float* __restrict__ wt, float* __restrict__ y,
-                   int64_t N, int I, int O, int G, int act, int PT, int NIC) {
+                   int64_t N, int I, int O, int G, int act, int PT, int NIC, int i0, int IB, int accumulate) {
   constexpr int J = 1 + D + D2;
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  const int IBe = (I - i0 < IB) ? (I - i0) : IB;          // features of this window
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EdgeRec* recs = reinterpret_cast<EdgeRec*>(smem);
-  float* s_jet = reinterpret_cast<float*>(recs + PT * I);
-  float* s_knots = s_jet + PT * I * J;
-  load_knots_to_lds(s_knots, grid, ginfo, 0, I, I, nk);
+  float* s_jet = reinterpret_cast<float*>(recs + PT * IB);
+  float* s_knots = s_jet + PT * IB * J;
+  load_knots_to_lds(s_knots, grid, ginfo, i0, IBe, I, nk);
   __syncthreads();
 
   const int64_t p0 = (int64_t)blockIdx.x * PT;
   const int npts = (int)((N - p0 < PT) ? (N - p0) : PT);
 
-  for (int pair = threadIdx.x; pair < npts * I; pair += blockDim.x) {
-    const int i = pair % I;
-    const float* src = a + (p0 * I + pair) * J;
+  for (int pair = threadIdx.x; pair < npts * IBe; pair += blockDim.x) {
+    const int i = pair % IBe, pl = pair / IBe;
+    const float* src = a + ((p0 + pl) * I + i0 + i) * J;
     float jet[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
@@ -141,10 +144,10 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = 0.0f;
     if (live) {
-      for (int i = ic; i < I; i += NIC) {
-        const EdgeRec r = recs[p * I + i];
-        const float* jet = s_jet + (p * I + i) * J;
-        const float* wcol = wt + (size_t)(i * C1) * O + o;
+      for (int i = ic; i < IBe; i += NIC) {
+        const EdgeRec r = recs[p * IBe + i];
+        const float* jet = s_jet + (p * IBe + i) * J;
+        const float* wcol = wt + (size_t)((i0 + i) * C1) * O + o;
         const float wb = wcol[(size_t)C * O];
         float p0v = wb * r.f0, p1v = wb * r.f1, p2v = wb * r.f2;
 #pragma unroll
@@ -165,7 +168,7 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
     if (live && ic == 0) {
       float* dst = y + ((p0 + p) * O + o) * J;
 #pragma unroll
-      for (int j = 0; j < J; ++j) dst[j] = acc[j];
+      for (int j = 0; j < J; ++j) dst[j] = accumulate ? dst[j] + acc[j] : acc[j];
     }
   }
 }
@@ -180,23 +183,26 @@ template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
                          const float* __restrict__ grid, const float* __restrict__ ginfo, const float* __restrict__ wp,
-                         float* __restrict__ ga, int64_t N, int I, int O, int G, int act) {
+                         float* __restrict__ ga, int64_t N, int I, int O, int G, int act, int i0, int IB) {
   constexpr int J = 1 + D + D2;
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  const int IBe = (I - i0 < IB) ? (I - i0) : IB;          // this launch covers features [i0, i0 + IBe)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_knots = reinterpret_cast<float*>(smem);
-  load_knots_to_lds(s_knots, grid, ginfo, 0, I, I, nk);
+  load_knots_to_lds(s_knots, grid, ginfo, i0, IBe, I, nk);
   __syncthreads();
-  const int64_t total = N * I;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = t / I;
-    const int i = (int)(t % I);
+  const int64_t total = N * IBe;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total;
+       u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = u / IBe;
+    const int il = (int)(u % IBe);
+    const int i = i0 + il;
+    const int64_t t = p * I + i;
     float jet[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) jet[j] = a[t * J + j];
     Basis bs;
-    eval_basis_row<true>(s_knots + i * (nk + 1), nk, jet[0], bs);
+    eval_basis_row<true>(s_knots + il * (nk + 1), nk, jet[0], bs);
     const Act av = eval_act(act, jet[0]);
     float Gm[5][J];
 #pragma unroll
@@ -475,33 +481,43 @@ static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, 
   seed_jets_kernel<D, D2><<<(int)blocks, 256, 0, st>>>(x, sn, sd, a, N, I);
 }
 
+// input features per launch of the streaming forward / input-gradient kernels: bounds their LDS footprint
+// (the forward launcher narrows it further when a large grid would push a window past 60 KB)
+constexpr int kGenericWindow = 256;
+
 template <int D, int D2>
 static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
   constexpr int J = 1 + D + D2;
-  int PT = 256 / L.I; if (PT < 1) PT = 1; if (PT > 64) PT = 64;
+  int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
+  const int per_feature = (int)sizeof(EdgeRec) + J * 4 + (L.nk() + 1) * 4;
+  if (IB * per_feature > 60 * 1024) IB = (60 * 1024) / per_feature;    // large grids: narrower window
+  int PT = 256 / IB; if (PT < 1) PT = 1; if (PT > 64) PT = 64;
   int NIC = 1;
   if (PT * L.O < 256) {
     NIC = pow2_floor(256 / (PT * L.O));
-    const int cap = pow2_floor(L.I);
+    const int cap = pow2_floor(IB);
     if (NIC > cap) NIC = cap;
     if (NIC > 64) NIC = 64;
   }
-  const size_t lds = (size_t)PT * L.I * (sizeof(EdgeRec) + J * 4) + (size_t)L.I * (L.nk() + 1) * 4;
+  const size_t lds = (size_t)PT * IB * (sizeof(EdgeRec) + J * 4) + (size_t)IB * (L.nk() + 1) * 4;
   const int64_t blocks = (N + PT - 1) / PT;
-  fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act, PT,
-                                                                NIC);
+  for (int i0 = 0; i0 < L.I; i0 += IB)
+    fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act,
+                                                                  PT, NIC, i0, IB, i0 > 0);
 }
 
 template <int D, int D2>
 static void bwd_input_t(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
                         int64_t N, hipStream_t st) {
-  const int64_t total = N * L.I;
+  const int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
+  const int64_t total = N * IB;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
-  const size_t lds = (size_t)L.I * (L.nk() + 1) * 4;
-  bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, L.ginfo, wp, ga, N, L.I, L.O, L.G,
-                                                                 L.act);
+  const size_t lds = (size_t)IB * (L.nk() + 1) * 4;
+  for (int i0 = 0; i0 < L.I; i0 += IB)
+    bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, L.ginfo, wp, ga, N, L.I, L.O, L.G,
+                                                                   L.act, i0, IB);
 }
 
 static inline int pow2_ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }

@@ -324,3 +324,38 @@ def test_moved_grid_takes_the_general_basis_path():
             n = ref["grads"][l][k].numel()
             assert max_rel(step.flat_grad[off:off + n].cpu(), ref["grads"][l][k].flatten()) <= TOL, (l, k)
             off += n
+
+
+@pytest.mark.parametrize("widths,G,N", [([600, 2, 1], 5, 7), ([3000, 2, 1], 5, 1), ([300, 3, 1], 64, 5)])
+def test_wide_input_layer_matches_oracle(widths, G, N):
+    """Layers wider than one LDS window of the streaming kernels (the branch
+    network KAN([3000, 2, 1]) of run1.py:481, evaluated on a single row as all its
+    rows are equal, run1.py:112): values, input and parameter gradients."""
+    from pde_amd import KAN
+    torch.manual_seed(5)
+    m = KAN(widths, grid_size=G, base_activation=torch.nn.Identity)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    layers = O.layers_from_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    layers64 = O.layers_from_state_dict({k: v.clone() for k, v in m.state_dict().items()}, dtype=torch.float64)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(N, widths[0], generator=g) * 2.4 - 1.2          # some inputs fall outside the grid range
+    gy = torch.linspace(-1.0, 1.0, N).view(N, 1)
+    ref = O.value_step(x.double(), layers64, "identity", gy.double())
+    ref32 = O.value_step(x, layers, "identity", gy)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    (y * gy.cuda()).sum().backward()
+
+    def close(val, r64, r32, what):
+        v = val.detach().cpu()
+        assert max_rel(v, r64) <= TOL, (what, max_rel(v, r64))
+        assert max_rel(v, r32) <= TOL + max_rel(r32, r64), (what, max_rel(v, r32))
+
+    close(y, ref["y"], ref32["y"], "y")
+    close(xg.grad, ref["gx"], ref32["gx"], "gx")
+    for l, layer in enumerate(m.layers):
+        for key in ("base_weight", "spline_weight", "spline_scaler"):
+            close(getattr(layer, key).grad, ref["grads"][l][key], ref32["grads"][l][key], f"{l}.{key}")
