@@ -1,0 +1,139 @@
+"""Black-Scholes PI-DeepONet training on pde_amd: the run of the reference's
+run1.py (data generation :271-423, models :478-482, loop :197-241, evaluation
+:492-523) on one MI355X.
+
+What differs from the script, on purpose:
+  * random numbers come from numpy (the script draws them with jax.random, which
+    this image does not have); the distributions and shapes are the script's,
+    except that the time column of the second sensor network is a regular grid
+    where the script interpolates a Gaussian-process draw (run1.py:283-297);
+  * the market file data.csv is not shipped; the trained network is scored
+    against the closed-form European call (the formula of B-S.py:5-17) on a grid
+    of (S, t) instead, with the script's error measures (run1.py:511-523);
+  * the network classes are pde_amd's (HIP kernels), not efficient_kan's.
+
+    python examples/run1_pi_deeponet.py --epochs 50
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+S_MAX, STRIKE, RATE, SIGMA = 7.233, 2.411, 0.025610, 0.165856529     # run1.py:285, 429-434
+
+
+def min_max_normalize(x, lo, hi):
+    return (x - lo) / (hi - lo)                                        # run1.py:261-263
+
+
+def generate_training_data(rng: np.random.Generator, P: int, Q: int):
+    """run1.py:271-423 with numpy draws.  Returns sensor inputs u_1, u_2 [P/3, 3],
+    boundary/initial points (x_i, t_i, outputs_i) [P], collocation points
+    (x_b, t_b, outputs_b) [Q] and the normalisation constants."""
+    m = P // 3
+    payoff = lambda x: np.maximum(x - STRIKE, 0.0)                     # f1 at t = 0, run1.py:251-252
+    x_bc1 = rng.uniform(0, S_MAX, (m, 1)); t_bc1 = np.zeros((m, 1))    # initial condition
+    x_bc2 = S_MAX * np.ones((m, 1)); t_bc2 = rng.uniform(0, 1, (m, 1)) # far boundary
+    x_bc3 = np.zeros((m, 1)); t_bc3 = rng.uniform(0, 1, (m, 1))        # S = 0
+    x_bcs = np.vstack([x_bc1, x_bc2, x_bc3]); t_bcs = np.vstack([t_bc1, t_bc2, t_bc3])
+    x_lo, x_hi, t_lo, t_hi = x_bcs.min(), x_bcs.max(), t_bcs.min(), t_bcs.max()
+    s_bc1 = payoff(x_bc1)
+    s_bc2 = np.where(x_bc2 == S_MAX, x_bc2 - STRIKE, 10.0)            # f2, run1.py:253-254
+    s_bc3 = np.zeros((m, 1))                                           # f3
+    s_train = np.vstack([s_bc1, s_bc2, s_bc3])
+    s_lo, s_hi = s_train.min(), s_train.max()
+    x_b = rng.uniform(0, S_MAX, (Q, 1)); t_b = rng.uniform(0, 1, (Q, 1))
+
+    # sensors: the payoff on a regular S grid at t = 0, and the far boundary on a regular t grid
+    grid_x = np.linspace(0, S_MAX, m).reshape(-1, 1)
+    grid_t = np.linspace(0, 1, m).reshape(-1, 1)
+    u_1 = np.hstack([min_max_normalize(grid_x, x_lo, x_hi), min_max_normalize(t_bc1, t_lo, t_hi),
+                     min_max_normalize(payoff(grid_x), s_lo, s_hi)])
+    u_2 = np.hstack([min_max_normalize(x_bc2, x_lo, x_hi), min_max_normalize(grid_t, t_lo, t_hi),
+                     min_max_normalize(s_bc2, s_lo, s_hi)])
+    f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    data = dict(
+        u_1=f(u_1), u_2=f(u_2),
+        x_i=f(min_max_normalize(x_bcs, x_lo, x_hi)).reshape(-1), t_i=f(min_max_normalize(t_bcs, t_lo, t_hi)).reshape(-1),
+        outputs_i=f(min_max_normalize(s_train, s_lo, s_hi)).reshape(-1),
+        x_b=f(min_max_normalize(x_b, x_lo, x_hi)).reshape(-1), t_b=f(min_max_normalize(t_b, t_lo, t_hi)).reshape(-1),
+        outputs_b=torch.zeros(Q),
+    )
+    norm = dict(x=(x_lo, x_hi), t=(t_lo, t_hi), s=(s_lo, s_hi))
+    return data, norm
+
+
+def black_scholes_call(S, K, T, r, sigma):
+    """Closed-form European call, time to expiry T."""
+    S = np.maximum(S, 1e-12); T = np.maximum(T, 1e-12)
+    d1 = (np.log(S / K) + (r + 0.5 * sigma ** 2) * T) / (sigma * np.sqrt(T))
+    d2 = d1 - sigma * np.sqrt(T)
+    cdf = lambda z: 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0)))
+    return S * cdf(d1) - K * np.exp(-r * T) * cdf(d2)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--P", type=int, default=9000, help="boundary/initial points (run1.py:430)")
+    ap.add_argument("--Q", type=int, default=1000, help="collocation points (run1.py:431)")
+    ap.add_argument("--batch", type=int, default=100, help="run1.py:470-471")
+    ap.add_argument("--epochs", type=int, default=20, help="the script trains 1500 (run1.py:211)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    from pde_amd import KAN
+    from pde_amd.deeponet import PI_DeepONet
+
+    dev = torch.device("cuda")
+    torch.manual_seed(args.seed)
+    data, norm = generate_training_data(np.random.default_rng(args.seed), args.P, args.Q)
+    data = {k: v.to(dev) for k, v in data.items()}
+    ident = torch.nn.Identity
+    m = args.P // 3
+    net = PI_DeepONet(KAN([3, 2, 1], base_activation=ident), KAN([3, 2, 1], base_activation=ident),
+                      KAN([m, 2, 1], base_activation=ident), KAN([2, 6, 1], base_activation=ident)).to(dev)  # run1.py:478-482
+    gen = torch.Generator().manual_seed(args.seed)
+    dl1 = DataLoader(TensorDataset(data["x_i"], data["t_i"], data["outputs_i"]), batch_size=args.batch, shuffle=True,
+                     generator=gen)
+    dl2 = DataLoader(TensorDataset(data["x_b"], data["t_b"], data["outputs_b"]), batch_size=args.batch, shuffle=True,
+                     generator=gen)
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01)                 # run1.py:209
+    u_s1, u_s2 = data["u_1"][:, 2], data["u_2"][:, 2]
+    t0 = time.time()
+    history = []
+    for epoch in range(args.epochs):
+        for bc_batch, pde_batch in zip(dl1, dl2):
+            loss, pde_loss, bc_loss = net.train_step(opt, data["u_1"], data["u_2"], u_s1, u_s2, bc_batch, pde_batch)
+        history.append((float(pde_loss), float(bc_loss)))
+        print(f"epoch {epoch:4d}  pde loss {history[-1][0]:.3e} | bc loss {history[-1][1]:.3e}", flush=True)
+    torch.cuda.synchronize()
+    train_s = time.time() - t0
+
+    # evaluation (run1.py:492-523) against the closed form on a grid; tau = 1 - t is the time to expiry in years
+    S = np.linspace(1.5, 3.5, 41); tt = np.linspace(0.05, 0.95, 10)
+    Sg, Tg = np.meshgrid(S, tt)
+    x_test = torch.tensor(min_max_normalize(Sg.reshape(-1), *norm["x"]), dtype=torch.float32, device=dev)
+    t_test = torch.tensor(min_max_normalize(Tg.reshape(-1), *norm["t"]), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        s_pred = net.operator_net(data["u_1"], data["u_2"], u_s1, u_s2, x_test, t_test) * float(norm["s"][1])
+    s_true = torch.tensor(black_scholes_call(Sg.reshape(-1), STRIKE, Tg.reshape(-1), RATE, SIGMA), dtype=torch.float32,
+                          device=dev)
+    mse = torch.mean((s_pred - s_true) ** 2).item()
+    mask = s_true > 1e-2
+    mape = (torch.mean(torch.abs((s_true[mask] - s_pred[mask]) / s_true[mask])) * 100).item()
+    print(f"MSE: {mse:.6e}\nRMSE: {math.sqrt(mse):.6e}\nMAPE (in-the-money points): {mape:.3f}%")
+    print(f"run-time: {train_s:.2f} s for {args.epochs} epochs x {min(len(dl1), len(dl2))} steps")
+    return {"history": history, "mse": mse, "mape": mape, "train_s": train_s}
+
+
+if __name__ == "__main__":
+    main()

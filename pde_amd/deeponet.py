@@ -1,0 +1,122 @@
+"""Physics-informed DeepONet over :class:`pde_amd.KAN` networks.
+
+Mirrors the ``PI_DeepONet`` class the reference scripts build around their four
+KANs (run1.py:75-149; same in run2.py:86-160, run3.py:87-161): two sensor
+networks whose outputs are multiplied (``brunk_net``), a mixing network on the
+flattened product (``model4``), a trunk network on ``(x, t)`` (``model5``), the
+prediction ``sum(branch * trunk, dim=1)``, the Black-Scholes residual and the
+two mean-squared losses.  Method names, argument order and return shapes are
+the reference's, so its training loop (run1.py:214-233) runs on this class
+unchanged.
+
+Two things are done differently, with identical results:
+
+* the reference feeds ``model4`` n copies of the same row
+  (``B1.view(1, -1).repeat(n, 1)``, run1.py:112); every row gives the same
+  output, so ``model4`` is evaluated once on the single row and broadcast;
+* the derivatives ``s_x, s_t, s_xx`` come from the trunk's input jets
+  (``KAN.forward_jet``, one O(n) kernel pass) instead of ``jacrev`` / ``hessian``
+  over the whole batch (run1.py:122-124, O(n^2) / O(n^3) temporaries).  The
+  branch factor does not depend on ``(x, t)``, so the jet of the prediction is the
+  branch factor times the jet of the trunk.
+
+Everything runs on the library kernels: there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from .kan import KAN
+from .pinn import BS_RATE, BS_SIGMA
+
+
+class PI_DeepONet(nn.Module):
+    def __init__(self, model1: KAN, model2: KAN, model4: KAN, model5: KAN, sigma: float = BS_SIGMA,
+                 rate: float = BS_RATE, bc_weight: float = 8.0):
+        super().__init__()
+        self.model1 = model1
+        self.model2 = model2
+        self.model4 = model4
+        self.model5 = model5
+        self.sigma = float(sigma)          # run1.py:126
+        self.rate = float(rate)            # run1.py:127
+        self.bc_weight = float(bc_weight)  # run1.py:224
+        self.bc_losses = []
+        self.pde_losses = []
+        if model4.layers[-1].out_features != model5.layers[-1].out_features:
+            raise ValueError("model4 and model5 must have the same output width (their product is summed over it)")
+        if model5.layers[0].in_features != 2:
+            raise ValueError("the trunk network takes (x, t)")
+
+    # ---- pieces with the reference's names ---------------------------------
+    def reshape(self, X: torch.Tensor) -> torch.Tensor:
+        return X.reshape(-1,)
+
+    def brunk_net(self, u1, u2, u_s1=None, u_s2=None) -> torch.Tensor:
+        """run1.py:92-98: product of the two sensor networks, [sensors, 1]."""
+        return self.model1(u1) * self.model2(u2)
+
+    def helper(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """run1.py:101-106: [n, 2] view with strides (1, n); the kernels read it in place."""
+        return torch.stack([self.reshape(X), self.reshape(Y)]).permute(1, 0)
+
+    def branch_row(self, u1, u2, u_s1=None, u_s2=None) -> torch.Tensor:
+        """model4 on the flattened sensor product, evaluated once: [1, p]."""
+        prod = self.brunk_net(u1, u2, u_s1, u_s2)
+        return self.model4(prod.reshape(1, -1).float())
+
+    def operator_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """run1.py:109-117: prediction at the n points, shape [n]."""
+        B = self.branch_row(u1, u2, u_s1, u_s2)
+        T = self.model5(self.helper(x, t))
+        return torch.sum(B * T, dim=1)
+
+    def operator_jet(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """(s, s_x, s_t, s_xx) at the n points, shape [n, 4]."""
+        B = self.branch_row(u1, u2, u_s1, u_s2)                       # [1, p]
+        T = self.model5.forward_jet(self.helper(x, t))                # [n, p, 4]
+        return torch.sum(B.unsqueeze(-1) * T, dim=1)
+
+    def residual_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """run1.py:120-129."""
+        jet = self.operator_jet(u1, u2, u_s1, u_s2, x, t)
+        s, s_x, s_t, s_xx = jet[:, 0], jet[:, 1], jet[:, 2], jet[:, 3]
+        x = self.reshape(x)
+        return s_t - 0.5 * self.sigma ** 2 * x ** 2 * s_xx - self.rate * x * s_x + self.rate * s
+
+    def loss_bcs(self, u1, u2, u_s1, u_s2, x, t, output) -> torch.Tensor:
+        """run1.py:134-141."""
+        s_pred = self.operator_net(u1, u2, u_s1, u_s2, x, t)
+        return torch.mean((output.flatten() - s_pred) ** 2)
+
+    def loss_res(self, u1, u2, u_s1, u_s2, x, t, output) -> torch.Tensor:
+        """run1.py:145-149."""
+        pred = self.residual_net(u1, u2, u_s1, u_s2, x, t)
+        return torch.mean((output.flatten() - pred) ** 2)
+
+    # ---- one optimiser step, as the loop body of run1.py:217-233 -----------
+    def train_step(self, optimizer: torch.optim.Optimizer, u1, u2, u_s1, u_s2, bc_batch: Sequence[torch.Tensor],
+                   pde_batch: Sequence[torch.Tensor]):
+        x_i, t_i, outputs_i = bc_batch
+        x_b, t_b, outputs_b = pde_batch
+        optimizer.zero_grad()
+        bc_loss = self.loss_bcs(u1, u2, u_s1, u_s2, x_i, t_i, outputs_i)
+        pde_loss = self.loss_res(u1, u2, u_s1, u_s2, x_b, t_b, outputs_b)
+        loss = pde_loss + self.bc_weight * bc_loss
+        loss.backward()
+        optimizer.step()
+        return loss.detach(), pde_loss.detach(), bc_loss.detach()
+
+    def fit(self, u1, u2, u_s1, u_s2, dataloader1, dataloader2, epochs: int = 1500, lr: float = 0.01,
+            optimizer: Optional[torch.optim.Optimizer] = None):
+        """run1.py:197-241: AdamW(lr=0.01) over the zipped boundary / collocation loaders."""
+        opt = optimizer or torch.optim.AdamW(self.parameters(), lr=lr)
+        for _ in range(epochs):
+            for bc_batch, pde_batch in zip(dataloader1, dataloader2):
+                _, pde_loss, bc_loss = self.train_step(opt, u1, u2, u_s1, u_s2, bc_batch, pde_batch)
+            self.pde_losses.append(pde_loss)
+            self.bc_losses.append(bc_loss)
+        return self

@@ -50,3 +50,7 @@ def golden():
         return cache[name]
 
     return get
+
+
+DEEPONET_CASES = ["deeponet_run1", "deeponet_wide"]
+DEEPONET_MODELS = ("model1", "model2", "model4", "model5")

@@ -149,6 +149,88 @@ def make_jacrev_case():
     print("jacrev_hessian: ok")
 
 
+def make_deeponet(name, sensors, w12, w4, w5, seed, n, bc_weight, steps=3):
+    """The physics-informed DeepONet of run1.py:75-149 on the reference's KAN class:
+    model1(u1)*model2(u2) flattened to one row, repeated n times into model4
+    (run1.py:109-113), trunk model5 on (x, t), sum of branch*trunk (:116);
+    derivatives by jacrev/hessian (:121-124); loss = pde + w*bc (:224); then
+    `steps` AdamW(lr=0.01) updates (:209, :217-233) with the losses recorded."""
+    from torch.func import hessian, jacrev
+    torch.manual_seed(seed)
+    ident = torch.nn.Identity
+    models = {"model1": KAN(w12, base_activation=ident), "model2": KAN(w12, base_activation=ident),
+              "model4": KAN(w4, base_activation=ident), "model5": KAN(w5, base_activation=ident)}
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for m in models.values():
+            for p in m.parameters():
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    u1 = torch.rand(sensors, w12[0], generator=gen)
+    u2 = torch.rand(sensors, w12[0], generator=gen)
+    x_i, t_i, out_i = torch.rand(n, generator=gen), torch.rand(n, generator=gen), torch.rand(n, generator=gen)
+    x_b, t_b, out_b = torch.rand(n, generator=gen), torch.rand(n, generator=gen), torch.zeros(n)
+
+    def evaluate(ms, cast, tag, rec):
+        c = lambda z: z.to(cast)
+
+        def net(xx, tt):
+            k = len(xx)
+            rows = (ms["model1"](c(u1)) * ms["model2"](c(u2))).view(1, -1).repeat(k, 1)
+            y = torch.stack([xx.reshape(-1), tt.reshape(-1)]).permute(1, 0)
+            return torch.sum(ms["model4"](rows) * ms["model5"](y), dim=1)
+
+        def all_losses():
+            s_pred = net(c(x_i), c(t_i))
+            bc_loss = torch.mean((c(out_i).flatten() - s_pred) ** 2)
+            xb, tb = c(x_b), c(t_b)
+            s = net(xb, tb)
+            s_x = jacrev(net, argnums=0)(xb, tb).sum(dim=0)
+            s_xx = hessian(net, argnums=0)(xb, tb).sum(dim=0).sum(dim=0)
+            s_t = jacrev(net, argnums=1)(xb, tb).sum(dim=0)
+            res = s_t - 0.5 * SIGMA ** 2 * xb ** 2 * s_xx - RATE * xb * s_x + RATE * s
+            pde_loss = torch.mean((c(out_b).flatten() - res) ** 2)
+            return s_pred, res, bc_loss, pde_loss, pde_loss + bc_weight * bc_loss
+
+        for m in ms.values():
+            m.zero_grad()
+        s_pred, res, bc_loss, pde_loss, loss = all_losses()
+        loss.backward()
+        rec[f"s_pred{tag}"] = s_pred.detach().numpy()
+        rec[f"res{tag}"] = res.detach().numpy()
+        rec[f"bc_loss{tag}"] = bc_loss.detach().numpy()
+        rec[f"pde_loss{tag}"] = pde_loss.detach().numpy()
+        rec[f"loss{tag}"] = loss.detach().numpy()
+        for mname, m in ms.items():
+            for pname, p in m.named_parameters():
+                rec[f"grad{tag}.{mname}.{pname}"] = p.grad.detach().numpy().copy()
+        params = [p for m in ms.values() for p in m.parameters()]
+        opt = torch.optim.AdamW(params, lr=0.01)
+        trace = []
+        for _ in range(steps):
+            opt.zero_grad()
+            _, _, _, _, loss = all_losses()
+            loss.backward()
+            opt.step()
+            trace.append(float(loss.detach()))
+        rec[f"adamw_losses{tag}"] = np.array(trace)
+        rec[f"adamw_final{tag}.model5.layers.0.spline_weight"] = ms["model5"].layers[0].spline_weight.detach().numpy().copy()
+
+    rec = {"sensors": np.array(sensors), "w12": np.array(w12), "w4": np.array(w4), "w5": np.array(w5),
+           "grid_size": np.array(5), "act": np.array("identity"), "bc_weight": np.array(float(bc_weight)),
+           "sigma": np.array(SIGMA), "rate": np.array(RATE),
+           "u1": u1.numpy(), "u2": u2.numpy(), "x_i": x_i.numpy(), "t_i": t_i.numpy(), "out_i": out_i.numpy(),
+           "x_b": x_b.numpy(), "t_b": t_b.numpy(), "out_b": out_b.numpy()}
+    for mname, m in models.items():
+        for k, v in m.state_dict().items():
+            rec[f"sd.{mname}.{k}"] = v.numpy().copy()
+    m64 = {k: copy.deepcopy(m).double() for k, m in models.items()}
+    evaluate(models, torch.float32, "", rec)
+    evaluate(m64, torch.float64, "64", rec)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: loss={float(rec['loss']):.6e} adamw={rec['adamw_losses']} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     make("cfg1_silu", [2, 5, 1], 5, "silu", 0, 200)
     make("cfg1_identity", [2, 5, 1], 5, "identity", 1, 200)
@@ -160,3 +242,5 @@ if __name__ == "__main__":
     make("updated_grid", [2, 8, 1], 5, "silu", 6, 128, update_grid=True)
     make("deeponet_trunk", [2, 6, 1], 5, "identity", 9, 100)
     make_jacrev_case()
+    make_deeponet("deeponet_run1", 12, [3, 2, 1], [12, 2, 1], [2, 6, 1], 11, 16, 8.0)      # shapes of run1.py:478-482
+    make_deeponet("deeponet_wide", 10, [3, 2, 1], [10, 2, 2], [2, 5, 2], 12, 20, 200.0)    # latent width 2 (the 3-branch script's model4)

@@ -1,0 +1,104 @@
+"""pde_amd.deeponet.PI_DeepONet (HIP kernels through the C ABI) against the
+fixtures made from the reference's KAN class under the reference formulation
+(run1.py:75-149, 209-233)."""
+import pytest
+import torch
+
+from conftest import DEEPONET_CASES, DEEPONET_MODELS, golden_state_dict, max_rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def build(rec):
+    from pde_amd import KAN
+    from pde_amd.deeponet import PI_DeepONet
+    widths = {"model1": rec["w12"], "model2": rec["w12"], "model4": rec["w4"], "model5": rec["w5"]}
+    models = {}
+    for name in DEEPONET_MODELS:
+        m = KAN([int(w) for w in widths[name]], grid_size=int(rec["grid_size"]), base_activation=torch.nn.Identity)
+        m.load_state_dict(golden_state_dict(rec, prefix=f"sd.{name}."))
+        models[name] = m
+    net = PI_DeepONet(models["model1"], models["model2"], models["model4"], models["model5"],
+                      sigma=float(rec["sigma"]), rate=float(rec["rate"]), bc_weight=float(rec["bc_weight"]))
+    return net.cuda()
+
+
+def tensors(rec):
+    t = lambda k: torch.from_numpy(rec[k]).cuda()
+    return t("u1"), t("u2"), (t("x_i"), t("t_i"), t("out_i")), (t("x_b"), t("t_b"), t("out_b"))
+
+
+def check(val, rec, key, tol=TOL):
+    r32, r64 = rec[key], rec[key.replace(".", "64.", 1) if "." in key else key + "64"]
+    v = val.detach().cpu()
+    assert max_rel(v, r64) <= tol, (key, max_rel(v, r64))
+    assert max_rel(v, r32) <= tol + max_rel(r32, r64), (key, max_rel(v, r32))
+
+
+@pytest.mark.parametrize("case", DEEPONET_CASES)
+def test_losses_and_gradients_match_reference(golden, case):
+    rec = golden(case)
+    net = build(rec)
+    u1, u2, bc, pde = tensors(rec)
+    s_pred = net.operator_net(u1, u2, None, None, bc[0], bc[1])
+    res = net.residual_net(u1, u2, None, None, pde[0], pde[1])
+    bc_loss = net.loss_bcs(u1, u2, None, None, *bc)
+    pde_loss = net.loss_res(u1, u2, None, None, *pde)
+    loss = pde_loss + net.bc_weight * bc_loss
+    loss.backward()
+    check(s_pred, rec, "s_pred")
+    check(res, rec, "res")
+    check(bc_loss, rec, "bc_loss")
+    check(pde_loss, rec, "pde_loss")
+    check(loss, rec, "loss")
+    for mname in DEEPONET_MODELS:
+        for pname, p in getattr(net, mname).named_parameters():
+            check(p.grad, rec, f"grad.{mname}.{pname}")
+
+
+@pytest.mark.parametrize("case", DEEPONET_CASES)
+def test_adamw_steps_follow_the_reference(golden, case):
+    """Three AdamW(lr=0.01) steps of the loop body run1.py:217-233: the loss
+    trace and one updated tensor."""
+    rec = golden(case)
+    net = build(rec)
+    u1, u2, bc, pde = tensors(rec)
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01)
+    trace = []
+    for _ in range(len(rec["adamw_losses"])):
+        loss, _, _ = net.train_step(opt, u1, u2, None, None, bc, pde)
+        trace.append(loss.item())
+    assert max_rel(torch.tensor(trace), rec["adamw_losses64"]) <= 2e-5
+    w = net.model5.layers[0].spline_weight
+    assert max_rel(w.detach().cpu(), rec["adamw_final64.model5.layers.0.spline_weight"]) <= 2e-5
+
+
+def test_column_inputs_and_strided_points(golden):
+    """The scripts hand x, t as [n] tensors from a DataLoader (run1.py:455-473) and
+    as [n, 1] columns at evaluation (run1.py:495-503): same numbers either way."""
+    rec = golden("deeponet_run1")
+    net = build(rec)
+    u1, u2, bc, _ = tensors(rec)
+    a = net.operator_net(u1, u2, None, None, bc[0], bc[1])
+    b = net.operator_net(u1, u2, None, None, bc[0].unsqueeze(1), bc[1].unsqueeze(1))
+    assert torch.equal(a, b)
+    j = net.operator_jet(u1, u2, None, None, bc[0], bc[1])
+    assert j.shape == (bc[0].numel(), 4)
+    assert torch.equal(j[:, 0], a)
+
+
+def test_example_training_run_learns():
+    """examples/run1_pi_deeponet.py end to end at a reduced size: finite losses,
+    and the boundary loss falls over the epochs."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run1_pi_deeponet.py")
+    spec = importlib.util.spec_from_file_location("run1_pi_deeponet", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--P", "300", "--Q", "200", "--batch", "100", "--epochs", "12", "--seed", "0"])
+    hist = torch.tensor(out["history"])
+    assert torch.isfinite(hist).all()
+    assert hist[-3:, 1].mean() < hist[:3, 1].mean()
+    assert out["mse"] == out["mse"]
