@@ -201,14 +201,18 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
 #pragma unroll
   for (int o = 0; o < 32; ++o) { accl[o] = (f32x2){0.f, 0.f}; acch[o] = (f32x2){0.f, 0.f}; }
 
+  // The basis of feature i+1 is evaluated at the END of iteration i, before the barrier: the chain
+  // jet -> interval -> basis -> slot then overlaps the other waves' way to the barrier, and the first
+  // weight reads go out right after it.
+  barrier_after_dma();                     // knots, table 0, jets of features 0..3
+  f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * kFS) * 4);
+  Live L = eval_live<false>(sK, nk, act, cur[0]);
+
   for (int i = 0; i < I; ++i) {
-    barrier_after_dma();                   // table i and staged jets visible; buffer (i+1)&1 free
     const int buf = i & 1;
     if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
     if ((i % kFS) == 0 && i + kFS < I)     // features i+4..i+7 into the other staging buffer
       jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
-    const f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (((i / kFS) & 1) * PW * kFS + pl * kFS + (i % kFS)) * 4);
-    const Live L = eval_live<false>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float s2 = cur[1] * cur[1];
     // expanded jets of the 4 live splines and of the base column
     f32x2 el[5], eh[5];
@@ -231,7 +235,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int cur = q % 3, nxt = (q + 2) % 3;
+      const int cq = q % 3, nxt = (q + 2) % 3;
       if (q + 2 < 8) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) wq[nxt][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 2) * 4 + k) * 64);
@@ -240,8 +244,8 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x2 w01 = lo2(wq[cur][k]), w23 = hi2(wq[cur][k]);
-        const f32x2 wb = (k < 2) ? lo2(bq[cur]) : hi2(bq[cur]);
+        const f32x2 w01 = lo2(wq[cq][k]), w23 = hi2(wq[cq][k]);
+        const f32x2 wb = (k < 2) ? lo2(bq[cq]) : hi2(bq[cq]);
         f32x2& tl = accl[q * 4 + k];
         f32x2& th = acch[q * 4 + k];
         pkfma_x(tl, el[0], w01); pkfma_x(th, eh[0], w01);
@@ -251,6 +255,12 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
         if (k & 1) { pkfma_y(tl, el[4], wb); pkfma_y(th, eh[4], wb); }
         else       { pkfma_x(tl, el[4], wb); pkfma_x(th, eh[4], wb); }
       }
+    }
+    if (i + 1 < I) {
+      const int n = i + 1;
+      cur = *reinterpret_cast<const f32x4*>(sJw + (((n / kFS) & 1) * PW * kFS + pl * kFS + (n % kFS)) * 4);
+      L = eval_live<false>(sK + n * kKnotPadS, nk, act, cur[0]);
+      barrier_after_dma();                 // table i+1 landed everywhere; table i no longer read
     }
   }
   if (live_pt) {
@@ -312,16 +322,18 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   }
   jets_stage<PW>(sJw, a, wr, I, 0);
 
+  // as in the forward kernel, the basis of feature i+1 is evaluated before the barrier that ends iteration i
+  barrier_after_dma();
+  f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * kFS) * 4);
+  Live L = eval_live<true>(sK, nk, act, cur[0]);
+
   for (int i = 0; i < I; ++i) {
-    barrier_after_dma();
     const int buf = i & 1;
     if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
     if ((i % kFS) == 0) {
       if (i > 0) flush_out(i - kFS);       // gradients of the previous 4 features, parked before the barrier
       if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
     }
-    const f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (((i / kFS) & 1) * PW * kFS + pl * kFS + (i % kFS)) * 4);
-    const Live L = eval_live<true>(sK + i * kKnotPadS, nk, act, cur[0]);
     const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
     const float* bb = sB + buf * O + g * 32;
     f32x2 Gl[5], Gh[5];                    // per live column: sums over outputs of w * cotangent, jets (0,1) | (2,3)
@@ -374,6 +386,12 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       for (int j = 0; j < 4; ++j) out[j] += __shfl_xor(out[j], off);
     }
     if (g == 0) *reinterpret_cast<f32x4*>(sOw + (pl * kFS + (i % kFS)) * 4) = out;
+    if (i + 1 < I) {
+      const int n = i + 1;
+      cur = *reinterpret_cast<const f32x4*>(sJw + (((n / kFS) & 1) * PW * kFS + pl * kFS + (n % kFS)) * 4);
+      L = eval_live<true>(sK + n * kKnotPadS, nk, act, cur[0]);
+      barrier_after_dma();
+    }
   }
   __syncthreads();
   flush_out(I - kFS);
