@@ -50,8 +50,35 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   const float hs2 = 0.5f * sigma * sigma;
   float loss_local = 0.0f;
 
-  for (int64_t p = (int64_t)blockIdx.x * nw + wave; p < N; p += (int64_t)gridDim.x * nw) {
+  // A wave works on one point at a time, so the loads of the NEXT point (its jets, coordinates and
+  // target) are issued before the current point's arithmetic: their HBM latency hides behind it.
+  const int64_t pstride = (int64_t)gridDim.x * nw;
+  const int64_t pfirst = (int64_t)blockIdx.x * nw + wave;
+  float jetn[NF][J], xsn[D2], tgtn = 0.0f;
+#define PDEKAN_HEAD_FETCH(PP)                                                          \
+  {                                                                                    \
+    const int64_t pp_ = ((PP) < N) ? (PP) : N - 1;                                     \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                   \
+      const int i_ = lane + 64 * f;                                                    \
+      const float* src_ = a + (pp_ * I + (i_ < I ? i_ : 0)) * J;                       \
+      _Pragma("unroll") for (int j = 0; j < J; ++j) jetn[f][j] = src_[j];              \
+    }                                                                                  \
+    _Pragma("unroll") for (int d = 0; d < D2; ++d) xsn[d] = x[pp_ * stride_n + d * stride_d]; \
+    tgtn = target ? target[pp_] : 0.0f;                                                \
+  }
+  PDEKAN_HEAD_FETCH(pfirst)
+
+  for (int64_t p = pfirst; p < N; p += pstride) {
     float jet[NF][J];
+    float xs[D2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < J; ++j) jet[f][j] = jetn[f][j];
+#pragma unroll
+    for (int d = 0; d < D2; ++d) xs[d] = xsn[d];
+    const float tgt = tgtn;
+    PDEKAN_HEAD_FETCH(p + pstride)
     Basis bs[NF];
     Act av[NF];
     float ph1[NF], ph2[NF], ph3[NF];
@@ -63,9 +90,6 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
       const int i = lane + 64 * f;
       const bool live = i < I;
       const int ic = live ? i : 0;
-      const float* src = a + (p * I + ic) * J;
-#pragma unroll
-      for (int j = 0; j < J; ++j) jet[f][j] = src[j];
       eval_basis_row<true>(s_knots + ic * kr, nk, jet[f][0], bs[f]);
       av[f] = eval_act(act, jet[f][0]);
       const float* w = s_w + ic * C1;
@@ -86,13 +110,10 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
 #pragma unroll
       for (int j = 0; j < J; ++j) y[j] += __shfl_xor(y[j], off);
     }
-    float xs[D2];
-#pragma unroll
-    for (int d = 0; d < D2; ++d) xs[d] = x[p * stride_n + d * stride_d];
     float res = y[D] + rate * y[0];
 #pragma unroll
     for (int d = 0; d < D2; ++d) res = res - hs2 * xs[d] * xs[d] * y[1 + D + d] - rate * xs[d] * y[1 + d];
-    const float diff = res - (target ? target[p] : 0.0f);
+    const float diff = res - tgt;
     if (lane == 0) {
       loss_local += diff * diff;
       if (res_out) res_out[p] = res;
@@ -135,6 +156,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
       }
     }
   }
+#undef PDEKAN_HEAD_FETCH
   if (lane == 0) s_loss[wave] = loss_local;
   __syncthreads();
   if (part) {

@@ -50,6 +50,7 @@ void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, i
 
 // kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
 bool sparse_eligible(int D, int D2, const LayerView& L);
+bool sparse_input_grad_eligible(int D, int D2, const LayerView& L);
 size_t sparse_table_floats(const LayerView& L);
 void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st);
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st);

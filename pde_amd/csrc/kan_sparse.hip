@@ -131,35 +131,36 @@ constexpr int kFS = 4;
 // WaveRows holds the wave's view of a [N][I][4] tensor: a wave-uniform base and
 // the per-lane element offsets of its chunks (rows past the end of the batch are
 // clamped onto the last live row for loads and masked for stores).
-template <int PW>
+template <int PW, int FS = kFS>
 struct WaveRows {
-  static constexpr int NV = (PW * kFS) / 64;
+  static constexpr int NV = (PW * FS) / 64;
+  static_assert((PW * FS) % 64 == 0, "whole 16-byte chunks per lane");
   int64_t base;      // first point of the wave (clamped into the batch), wave-uniform
   int nlive;         // live points of the wave, wave-uniform
   int off[NV];       // (row * I + feature-in-stage) * 4
 };
 
-template <int PW>
-__device__ __forceinline__ WaveRows<PW> wave_rows(int64_t P0, int64_t N, int I, int lane) {
-  WaveRows<PW> r;
+template <int PW, int FS = kFS>
+__device__ __forceinline__ WaveRows<PW, FS> wave_rows(int64_t P0, int64_t N, int I, int lane) {
+  WaveRows<PW, FS> r;
   int64_t left = N - P0;
   r.nlive = left <= 0 ? 0 : (left < PW ? (int)left : PW);
   r.base = r.nlive > 0 ? P0 : N - 1;
 #pragma unroll
-  for (int k = 0; k < WaveRows<PW>::NV; ++k) {
+  for (int k = 0; k < WaveRows<PW, FS>::NV; ++k) {
     const int c = lane + 64 * k;
-    const int row = c / kFS;
+    const int row = c / FS;
     const int rc = row < r.nlive ? row : (r.nlive > 0 ? r.nlive - 1 : 0);
-    r.off[k] = (rc * I + (c % kFS)) * 4;
+    r.off[k] = (rc * I + (c % FS)) * 4;
   }
   return r;
 }
 
-template <int PW>
-__device__ __forceinline__ void jets_stage(float* sJ, const float* a, const WaveRows<PW>& r, int I, int i0) {
+template <int PW, int FS = kFS>
+__device__ __forceinline__ void jets_stage(float* sJ, const float* a, const WaveRows<PW, FS>& r, int I, int i0) {
   const float* src = a + (r.base * I + i0) * 4;
 #pragma unroll
-  for (int k = 0; k < WaveRows<PW>::NV; ++k)
+  for (int k = 0; k < WaveRows<PW, FS>::NV; ++k)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r.off[k]),
                                      (__attribute__((address_space(3))) void*)(sJ + 64 * k * 4), 16, 0, 0);
 }
@@ -167,7 +168,7 @@ __device__ __forceinline__ void jets_stage(float* sJ, const float* a, const Wave
 // ==========================================================================
 // forward
 // ==========================================================================
-template <int O>
+template <int O, int FS>
 __global__ void __launch_bounds__(256, 2)
 fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                   const float* __restrict__ win,
@@ -178,8 +179,8 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);            // [2][O*64]
   float* sB = sT + 2 * O * 64;                           // [2][O]
-  float* sJ = sB + 2 * O;                                // [4 waves][2][PW][kFS][4] staged input jets
-  float* sK = sJ + 4 * 2 * PW * kFS * 4;                 // [I][kKnotPadS]
+  float* sJ = sB + 2 * O;                                // [4 waves][2][PW][FS][4] staged input jets
+  float* sK = sJ + 4 * 2 * PW * FS * 4;                 // [I][kKnotPadS]
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = lane / PW, pl = lane % PW;
@@ -187,15 +188,15 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   int64_t p = P0 + pl;
   const bool live_pt = p < N;
   if (!live_pt) p = N - 1;
-  float* sJw = sJ + wave * 2 * PW * kFS * 4;
-  const WaveRows<PW> wr = wave_rows<PW>(P0, N, I, lane);
+  float* sJw = sJ + wave * 2 * PW * FS * 4;
+  const WaveRows<PW, FS> wr = wave_rows<PW, FS>(P0, N, I, lane);
 
   for (int t = tid; t < I * (nk + 1); t += 256) {        // knot rows + the feature's 1/h (0 = not equally spaced)
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
   table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
-  jets_stage<PW>(sJw, a, wr, I, 0);
+  jets_stage<PW, FS>(sJw, a, wr, I, 0);
 
   f32x2 accl[32], acch[32];               // jets (0,1) and (2,3) of the lane's 32 outputs
 #pragma unroll
@@ -205,14 +206,14 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   // jet -> interval -> basis -> slot then overlaps the other waves' way to the barrier, and the first
   // weight reads go out right after it.
   barrier_after_dma();                     // knots, table 0, jets of features 0..3
-  f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * kFS) * 4);
+  f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * FS) * 4);
   Live L = eval_live<false>(sK, nk, act, cur[0]);
 
   for (int i = 0; i < I; ++i) {
     const int buf = i & 1;
     if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
-    if ((i % kFS) == 0 && i + kFS < I)     // features i+4..i+7 into the other staging buffer
-      jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
+    if ((i % FS) == 0 && i + FS < I)     // features i+4..i+7 into the other staging buffer
+      jets_stage<PW, FS>(sJw + (((i / FS) + 1) & 1) * PW * FS * 4, a, wr, I, i + FS);
     const float s2 = cur[1] * cur[1];
     // expanded jets of the 4 live splines and of the base column
     f32x2 el[5], eh[5];
@@ -258,15 +259,33 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     }
     if (i + 1 < I) {
       const int n = i + 1;
-      cur = *reinterpret_cast<const f32x4*>(sJw + (((n / kFS) & 1) * PW * kFS + pl * kFS + (n % kFS)) * 4);
+      cur = *reinterpret_cast<const f32x4*>(sJw + (((n / FS) & 1) * PW * FS + pl * FS + (n % FS)) * 4);
       L = eval_live<false>(sK + n * kKnotPadS, nk, act, cur[0]);
       barrier_after_dma();                 // table i+1 landed everywhere; table i no longer read
     }
   }
-  if (live_pt) {
-    f32x4* dst = reinterpret_cast<f32x4*>(y + (p * O + g * 32) * 4);
+  // Epilogue: a lane holds 32 outputs x 4 jets of one point (512 contiguous bytes in y).  Stored
+  // straight from registers every instruction would touch 64 different lines 16 bytes at a time, so the
+  // tile goes through LDS 8 outputs at a time and leaves as whole 128-byte lines (8 lanes per line).
+  __syncthreads();                                       // every wave is done with the tables
+  constexpr int LS = 36;                                 // floats per parked line: 32 + 4 pad (bank spread)
+  float* park = sT + wave * (64 * LS);                   // 64 lines per wave and pass; spans sT, sB and sJ
+  static_assert(4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * FS * 4, "parking area fits the staging buffers");
+  const int line_w = pl * OG + g;                        // the line this lane fills: (point, output group)
 #pragma unroll
-    for (int o = 0; o < 32; ++o) dst[o] = (f32x4){accl[o][0], accl[o][1], acch[o][0], acch[o][1]};
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = 8 * k + j;
+      *reinterpret_cast<f32x4*>(park + line_w * LS + j * 4) = (f32x4){accl[o][0], accl[o][1], acch[o][0], acch[o][1]};
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int line = (lane >> 3) + 8 * r, j = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(park + line * LS + j * 4);
+      const int64_t pp = P0 + line / OG;
+      if (pp < N) *reinterpret_cast<f32x4*>(y + (pp * O + (line % OG) * 32 + 8 * k + j) * 4) = v;
+    }
   }
 }
 
@@ -406,8 +425,14 @@ bool sparse_eligible(int D, int D2, const LayerView& L) {
   if (off && off[0] == '1') return false;
   if (L.G + 6 > kSlots) return false;
   if (L.O != 64 && L.O != 128) return false;
-  if (L.I < 8 || L.I > 256 || L.I % kFS != 0) return false;
-  return true;
+  // the forward kernel stages 4 features of a point at a time, or 2 (64 outputs only)
+  if (L.I < 2 || L.I > 256) return false;
+  return (L.I % 4 == 0) || (L.O == 64 && L.I % 2 == 0);
+}
+
+// the input-gradient kernel stages 4 features at a time
+bool sparse_input_grad_eligible(int D, int D2, const LayerView& L) {
+  return sparse_eligible(D, D2, L) && L.I >= 8 && L.I % kFS == 0;
 }
 
 size_t sparse_table_floats(const LayerView& L) { return (size_t)L.I * L.O * (kSlots * 4 + 1); }
@@ -420,9 +445,9 @@ void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStre
 }
 
 template <int O>
-static size_t sparse_lds(const LayerView& L, bool with_out_stage) {
+static size_t sparse_lds(const LayerView& L, bool with_out_stage, int fs = kFS) {
   constexpr int PW = 64 / (O / 32);
-  return (size_t)(2 * O * 64 + 2 * O + 4 * 2 * PW * kFS * 4 + (with_out_stage ? 4 * PW * kFS * 4 : 0) +
+  return (size_t)(2 * O * 64 + 2 * O + 4 * 2 * PW * fs * 4 + (with_out_stage ? 4 * PW * fs * 4 : 0) +
                   L.I * kKnotPadS) * 4;
 }
 
@@ -431,20 +456,22 @@ static void big_lds(Kern k, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
+template <int O, int FS>
+static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
   const float* wbt = win + (size_t)L.I * L.O * kSlots * 4;
+  constexpr int pts = 4 * (64 / (O / 32));               // points per block
+  auto k = fwd_sparse_kernel<O, FS>;
+  const size_t lds = sparse_lds<O>(L, false, FS);
+  big_lds(k, lds);
+  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
+}
+
+void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
   if (L.O == 64) {
-    const int pts = 4 * 32;
-    auto k = fwd_sparse_kernel<64>;
-    const size_t lds = sparse_lds<64>(L, false);
-    big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
+    if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st);
+    else fwd_sparse_launch<64, 2>(L, a, win, y, N, st);
   } else {
-    const int pts = 4 * 16;
-    auto k = fwd_sparse_kernel<128>;
-    const size_t lds = sparse_lds<128>(L, false);
-    big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
+    fwd_sparse_launch<128, 4>(L, a, win, y, N, st);
   }
 }
 

@@ -137,7 +137,7 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
                                  L.scaler ? g->spline_scaler : nullptr, accumulate, st);
   }
   if (ga) {
-    if (win && pdekan::sparse_eligible(D, D2, L)) {
+    if (win && pdekan::sparse_input_grad_eligible(D, D2, L)) {
       ProfScope ps(st, "L%d.bwd_input.sparse", li);
       pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st);
     } else if (mf) {

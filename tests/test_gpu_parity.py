@@ -269,7 +269,7 @@ def test_single_layer_model_step():
 
 @pytest.mark.parametrize("disable", ["PDEKAN_DISABLE_SPARSE", "PDEKAN_DISABLE_MFMA", None])
 @pytest.mark.parametrize("widths,G,N", [([2, 64, 64, 1], 10, 333), ([2, 64, 128, 64, 1], 10, 200),
-                                        ([2, 64, 64, 1], 5, 129)])
+                                        ([2, 64, 64, 1], 5, 129), ([2, 6, 64, 4, 128, 1], 10, 77)])
 def test_hidden_layer_paths_match_oracle(widths, G, N, disable, monkeypatch):
     """The same step through each hidden-layer path: sparse VALU forward/input
     gradients (default where eligible), dense MFMA only, streaming only."""
