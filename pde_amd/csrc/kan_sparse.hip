@@ -330,15 +330,34 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
-
-  // cotangents of this lane's 32 outputs stay in registers for the whole kernel
+  // cotangents of this lane's 32 outputs stay in registers for the whole kernel.  They are 512
+  // contiguous bytes per lane in gy; fetched as whole 128-byte lines (8 lanes per line) and handed to
+  // their lanes through LDS, 8 outputs at a time (the staging buffers are still unused here).
   f32x2 gyl[32], gyh[32];
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(gy + (p * O + g * 32) * 4);
+    constexpr int LS = 36;                               // floats per parked line: 32 + 4 pad (bank spread)
+    float* park = sT + wave * (64 * LS);
+    static_assert(4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * kFS * 4, "parking area fits the staging buffers");
+    const int line_w = pl * OG + g;                      // the line this lane consumes: (point, output group)
 #pragma unroll
-    for (int o = 0; o < 32; ++o) { const f32x4 v = src[o]; gyl[o] = lo2(v); gyh[o] = hi2(v); }
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int line = (lane >> 3) + 8 * r, j = lane & 7;
+        int64_t pp = P0 + line / OG;
+        if (pp > N - 1) pp = N - 1;
+        *reinterpret_cast<f32x4*>(park + line * LS + j * 4) =
+            *reinterpret_cast<const f32x4*>(gy + (pp * O + (line % OG) * 32 + 8 * k + j) * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(park + line_w * LS + j * 4);
+        gyl[8 * k + j] = lo2(v); gyh[8 * k + j] = hi2(v);
+      }
+    }
   }
+  __syncthreads();                                       // parking area released before the tables land in it
+  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
   jets_stage<PW>(sJw, a, wr, I, 0);
 
   // as in the forward kernel, the basis of feature i+1 is evaluated before the barrier that ends iteration i
