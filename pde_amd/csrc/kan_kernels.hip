@@ -344,20 +344,36 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
 
 // --------------------------------------------------------------------------
 // sum part[chunk][total] over the chunks into out[total]: a block takes 64
-// consecutive elements, its 4 waves take every 4th chunk each (coalesced 256-byte
-// reads), and the 4 partial sums are added in a fixed order.
+// consecutive elements, its 16 waves take every 16th chunk each (coalesced 256-byte
+// reads, 4 independent running sums per wave so the loads pipeline), and the
+// partial sums are added in a fixed order: bitwise reproducible.
 // --------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kSumWaves = 16;
+
+__global__ void __launch_bounds__(64 * kSumWaves)
 sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, float* __restrict__ out) {
-  __shared__ float s_r[4][64];
+  __shared__ float s_r[kSumWaves][64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + lane;
-  float s = 0.0f;
-  if (e < total)
-    for (int k = g; k < nchunks; k += 4) s += part[(size_t)k * total + e];
-  s_r[g][lane] = s;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (e < total) {
+    int k = g;
+    for (; k + 3 * kSumWaves < nchunks; k += 4 * kSumWaves) {
+      s0 += part[(size_t)k * total + e];
+      s1 += part[(size_t)(k + kSumWaves) * total + e];
+      s2 += part[(size_t)(k + 2 * kSumWaves) * total + e];
+      s3 += part[(size_t)(k + 3 * kSumWaves) * total + e];
+    }
+    for (; k < nchunks; k += kSumWaves) s0 += part[(size_t)k * total + e];
+  }
+  s_r[g][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && e < total) out[e] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
+  if (g == 0 && e < total) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kSumWaves; ++w) s += s_r[w][lane];
+    out[e] = s;
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -610,7 +626,7 @@ void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, fl
   const float* src = part;
   if (nchunks > 1) {
     const size_t total = L.packed_floats();
-    sum_partials_kernel<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(part, nchunks, total, sum_buf);
+    sum_partials_kernel<<<(unsigned)((total + 63) / 64), 64 * kSumWaves, 0, st>>>(part, nchunks, total, sum_buf);
     src = sum_buf;
   }
   const int blocks = (edges + 127) / 128;

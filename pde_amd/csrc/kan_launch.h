@@ -60,6 +60,10 @@ void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);
 int mfma_weight_chunks(int64_t N, const LayerView& L);
+bool mfma_skinny_weight_eligible(int D, int D2, const LayerView& L);   // 2-input layers: weight gradients only
+int mfma_skinny_weight_chunks(int64_t N, const LayerView& L);
+void launch_bwd_weight_mfma_skinny(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                                   int64_t N, hipStream_t st);
 void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st);
 void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
                            int64_t N, hipStream_t st);

@@ -333,6 +333,123 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 }
 
 // ==========================================================================
+// weight gradients of a layer with KI = 2 inputs (the first layer of a PINN on
+// (S, t)): all KI*C1 expanded columns fit two or three 16-wide tiles, so every
+// wave owns ALL columns x 64 outputs and the 4 waves of a block split the
+// points instead (8 per pass and wave, no block barrier inside the loop); their
+// accumulators are added through LDS at the end.  The E tile is built as in the
+// kernel above; the gY operand needs no LDS: in the 16x16x4 B layout lane
+// (n = lane&15, k = lane>>4) wants gY[point][output n][jet k], and a wave's 64
+// such dwords are 256 contiguous bytes of gy.
+// Output: part[chunk][O][KI][C1].
+// ==========================================================================
+template <int C1, int KI>
+__global__ void __launch_bounds__(256, 2)
+bwd_weight_mfma_skinny_kernel(const float4* __restrict__ a, const float* __restrict__ gy,
+                              const float* __restrict__ grid, const float* __restrict__ ginfo,
+                              float* __restrict__ part, int64_t N, int O, int act, int64_t chunk_pts) {
+  constexpr int COLS = KI * C1, NT = (COLS + 15) / 16, PB = 8, ROWS = PB * 4, RS = ROWS + 4;
+  constexpr int nk = C1 + 3;
+  static_assert(PB * KI <= 64, "one (point, feature) per lane");
+  static_assert(RS <= 64, "the E tiles fit the area later used for the final reduction");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sE = reinterpret_cast<float*>(smem);            // [4][NT*16][RS]; afterwards [4][NT*16][64] partial sums
+  float* sK = sE + 4 * NT * 16 * 64;                     // [KI][kKnotPad]   (64 >= RS: room for both uses)
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int p_local = lane % PB, f_local = lane / PB;
+  const bool gen_lane = f_local < KI;
+  const int o0 = blockIdx.y * 64;
+  float* tileE = sE + wave * NT * 16 * RS;
+  const int q = lane >> 4, l15 = lane & 15;
+
+  for (int idx = tid; idx < KI * (nk + 1); idx += 256) {
+    const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, f, k, nk);
+  }
+  for (int idx = lane; idx < NT * 16 * RS; idx += 64) tileE[idx] = 0.0f;     // pad columns stay zero
+  __syncthreads();
+  int prev_c0 = -100;
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t pbeg = (int64_t)blockIdx.x * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  const int loff = (o0 + l15) * 4 + q;                   // this lane's dword inside a point's row of gy
+
+  float bA[PB][4], bB[PB][4];
+  float4 jet = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (PBASE is wave-uniform: row addresses are scalar, only `loff` is per lane)
+#define PDEKAN_SKINNY_FETCH(BUF, PBASE)                                                  \
+  {                                                                                      \
+    if ((PBASE) + PB <= pend) {                                                          \
+      _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                   \
+        const float* row = gy + (size_t)((PBASE) + t) * O * 4;                           \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) BUF[t][m] = row[loff + m * 64];    \
+      }                                                                                  \
+    } else {                                                                             \
+      _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                   \
+        const int64_t pp = (PBASE) + t;                                                  \
+        const bool in = pp < pend;                                                       \
+        const float* row = gy + (size_t)(in ? pp : pbeg) * O * 4;                        \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) BUF[t][m] = in ? row[loff + m * 64] : 0.0f; \
+      }                                                                                  \
+    }                                                                                    \
+    if (gen_lane) {                                                                      \
+      int64_t pc = (PBASE) + p_local;                                                    \
+      if (pc > N - 1) pc = N - 1;                                                        \
+      jet = a[pc * KI + f_local];                                                        \
+    }                                                                                    \
+  }
+#define PDEKAN_SKINNY_PASS(BUF, BNEXT, PBASE)                                                          \
+  {                                                                                                    \
+    if (gen_lane) {                                                                                    \
+      float4 e[5];                                                                                     \
+      int c0;                                                                                          \
+      expand_jets(sK + f_local * kKnotPad, nk, act, jet, e, c0);                                       \
+      write_expanded<C1>(tileE, RS, f_local, p_local, e, c0, prev_c0, tileE + (f_local * C1) * RS + ROWS); \
+    }                                                                                                  \
+    PDEKAN_SKINNY_FETCH(BNEXT, (PBASE) + 4 * PB)                                                       \
+    _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                                   \
+      float fe[NT];                                                                                    \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) fe[n] = tileE[(n * 16 + l15) * RS + 4 * t + q];   \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                   \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                  \
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fe[n], BUF[t][m], acc[n][m], 0, 0, 0);      \
+    }                                                                                                  \
+  }
+  // wave w takes passes w, w+4, w+8, ... of the block's chunk, two per loop trip (register ping-pong)
+  int64_t pb = pbeg + (int64_t)wave * PB;
+  if (pb < pend) PDEKAN_SKINNY_FETCH(bA, pb)
+  for (; pb < pend; pb += 8 * PB) {
+    PDEKAN_SKINNY_PASS(bA, bB, pb)
+    if (pb + 4 * PB < pend) PDEKAN_SKINNY_PASS(bB, bA, pb + 4 * PB)
+  }
+#undef PDEKAN_SKINNY_PASS
+#undef PDEKAN_SKINNY_FETCH
+
+  // add the four waves' accumulators: D[column][output], lane holds columns n*16 + 4q + r of output m*16 + l15
+  __syncthreads();
+  float* red = sE + wave * (NT * 16 * 64);
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(n * 16 + 4 * q + r) * 64 + m * 16 + l15] = acc[n][m][r];
+  __syncthreads();
+  float* dst0 = part + ((size_t)blockIdx.x * O + o0) * COLS;
+  for (int idx = tid; idx < COLS * 64; idx += 256) {
+    const int o = idx / COLS, col = idx - o * COLS;
+    const float* src = sE + col * 64 + o;
+    dst0[(size_t)o * COLS + col] = (src[0] + src[NT * 16 * 64]) + (src[2 * NT * 16 * 64] + src[3 * NT * 16 * 64]);
+  }
+}
+
+// ==========================================================================
 // input-jet gradients: block = 4 waves x 8 points.  Per slab of KIS features
 //   gE[row][column] = sum_o gY[row][o] * W[o][column]       (16x16x4 MFMA, A = gY kept in registers)
 // then each (point, feature) lane pulls its 4+1 live columns out of LDS and
@@ -593,6 +710,43 @@ void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy,
   if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st);
   else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st);
   else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
+}
+
+bool mfma_skinny_weight_eligible(int D, int D2, const LayerView& L) {
+  if (D != 2 || D2 != 1) return false;
+  const char* off = getenv("PDEKAN_DISABLE_MFMA");
+  if (off && off[0] == '1') return false;
+  MfmaCfg c;
+  if (!cfg_for(L.G, c)) return false;
+  return L.I == 2 && L.O % 64 == 0 && L.O <= 256;
+}
+
+int mfma_skinny_weight_chunks(int64_t N, const LayerView& L) {
+  int64_t want = 768 / (L.O / 64);                      // three blocks per CU in flight (the register budget's limit)
+  const int64_t cap = (N + 255) / 256;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+template <int C1>
+static void bww_skinny_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
+                              hipStream_t st) {
+  constexpr int KI = 2, NT = (KI * C1 + 15) / 16;
+  const size_t lds = (size_t)(4 * NT * 16 * 64 + KI * kKnotPad) * 4;
+  int64_t chunk = (N + nchunks - 1) / nchunks;
+  chunk = (chunk + 31) / 32 * 32;
+  auto k = bwd_weight_mfma_skinny_kernel<C1, KI>;
+  allow_big_lds(k, lds);
+  dim3 g(nchunks, L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), gy, L.grid, L.ginfo, part, N, L.O, L.act, chunk);
+}
+
+void launch_bwd_weight_mfma_skinny(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                                   int64_t N, hipStream_t st) {
+  if (L.G == 10) bww_skinny_launch<14>(L, a, gy, part, nchunks, N, st);
+  else if (L.G == 20) bww_skinny_launch<24>(L, a, gy, part, nchunks, N, st);
+  else bww_skinny_launch<9>(L, a, gy, part, nchunks, N, st);
 }
 
 template <int C1, int KIS, int OT>

@@ -87,6 +87,7 @@ struct Carver {
 
 int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   if (pdekan::mfma_eligible(D, D2, L)) return pdekan::mfma_weight_chunks(n, L);
+  if (pdekan::mfma_skinny_weight_eligible(D, D2, L)) return pdekan::mfma_skinny_weight_chunks(n, L);
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }
 
@@ -127,6 +128,9 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
     if (mf) {
       ProfScope ps(st, "L%d.bwd_weight.mfma", li);
       pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st);
+    } else if (pdekan::mfma_skinny_weight_eligible(D, D2, L)) {
+      ProfScope ps(st, "L%d.bwd_weight.mfma_skinny", li);
+      pdekan::launch_bwd_weight_mfma_skinny(L, a, gy, part, nch, n, st);
     } else {
       ProfScope ps(st, "L%d.bwd_weight.stream", li);
       if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st))
