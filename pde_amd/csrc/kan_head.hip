@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "kan_math.h"
 #include "kan_launch.h"
+#include "kan_wave.h"
 
 namespace pdekan {
 
@@ -104,12 +105,9 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
       ph1[f] = p1; ph2[f] = p2; ph3[f] = p3;
       jet_accumulate<D, D2>(y, jet[f], p0, p1, p2);
     }
-    // wavefront butterfly: every lane ends up with the full sums
+    // wavefront sum on the VALU (DPP + permlane swaps): every lane ends up with the full sums
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) y[j] += __shfl_xor(y[j], off);
-    }
+    for (int j = 0; j < J; ++j) y[j] = wave_sum(y[j]);
     float res = y[D] + rate * y[0];
 #pragma unroll
     for (int d = 0; d < D2; ++d) res = res - hs2 * xs[d] * xs[d] * y[1 + D + d] - rate * xs[d] * y[1 + d];

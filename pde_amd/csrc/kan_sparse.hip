@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "kan_math.h"
 #include "kan_launch.h"
+#include "kan_wave.h"
 
 namespace pdekan {
 
@@ -418,11 +419,12 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       out[3] += q[3] * e1;
     }
     // add the output groups of one point (lanes pl, pl+PW, ...)
+    if (PW == 16) {
 #pragma unroll
-    for (int off = PW; off < 64; off <<= 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[j] += __shfl_xor(out[j], off);
+      for (int j = 0; j < 4; ++j) out[j] = sum_xor16(out[j]);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = sum_xor32(out[j]);
     if (g == 0) *reinterpret_cast<f32x4*>(sOw + (pl * kFS + (i % kFS)) * 4) = out;
     if (i + 1 < I) {
       const int n = i + 1;
