@@ -186,7 +186,7 @@ bool head_eligible(int D, const LayerView& L) {
 int head_blocks(int64_t N, const LayerView& L) {
   const int nw = head_waves(L);
   int64_t b = (N + (int64_t)nw * 16 - 1) / ((int64_t)nw * 16);
-  if (b > 1024) b = 1024;
+  if (b > 1280) b = 1280;                                 // 5 blocks per CU: the register budget's limit
   if (b < 1) b = 1;
   return (int)b;
 }
