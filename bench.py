@@ -140,7 +140,7 @@ def main():
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     step = BlackScholesStep(model, micro_batch=args.micro_batch)
     dp = DataParallelStep(step, dist) if dist is not None else None
-    opt = torch.optim.AdamW(model.parameters(), lr=0.01)   # run1.py:209
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, fused=True)   # run1.py:209; one launch for all tensors
 
     def one_step():
         if dp is not None:
