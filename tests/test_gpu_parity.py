@@ -359,3 +359,65 @@ def test_wide_input_layer_matches_oracle(widths, G, N):
     for l, layer in enumerate(m.layers):
         for key in ("base_weight", "spline_weight", "spline_scaler"):
             close(getattr(layer, key).grad, ref["grads"][l][key], ref32["grads"][l][key], f"{l}.{key}")
+
+
+def test_lbfgs_closure_on_the_fused_step():
+    """The LBFGS scripts (run2.py:174-195) drive the model through a closure that
+    zeroes the gradients, evaluates the loss and back-propagates.  With the fused
+    step as the closure body torch.optim.LBFGS (strong Wolfe, as the scripts
+    ask for) must see ordinary .grad tensors and reduce the loss."""
+    from pde_amd import KAN
+    from pde_amd.pinn import BlackScholesStep
+    torch.manual_seed(3)
+    m = KAN([2, 8, 1], grid_size=5).cuda()
+    x = torch.rand(2048, 2, generator=torch.Generator().manual_seed(4)).cuda()
+    step = BlackScholesStep(m)
+    opt = torch.optim.LBFGS(m.parameters(), lr=1.0, history_size=10, line_search_fn="strong_wolfe")
+    calls = []
+
+    def closure():
+        opt.zero_grad()                    # set_to_none: the step re-attaches its gradient views
+        loss = step(x)
+        calls.append(loss.item())
+        return loss
+
+    first = closure().item()
+    for _ in range(5):
+        opt.step(closure)
+    last = step(x).item()
+    assert len(calls) > 6 and all(v == v for v in calls)
+    assert last < 0.5 * first
+    # the gradients the optimiser consumed are the step's flat buffer
+    for p in m.parameters():
+        assert p.grad is not None and p.grad.data_ptr() >= step.flat_grad.data_ptr()
+
+
+def test_update_grid_on_device_matches_reference_fixture(golden):
+    """`model(x, update_grid=True)` (kan.py:274-279 with :168-215 per layer) on the
+    GPU: replays the call that produced the `updated_grid` fixture; both layers'
+    grids and refitted spline weights must come out as the reference's."""
+    from pde_amd import KAN
+    rec = golden("updated_grid")
+    seed = int(rec["seed"])
+    torch.manual_seed(seed)
+    m = KAN([2, 8, 1], grid_size=5)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    torch.rand(128, 2, generator=gen)                    # the fixture's points were drawn first
+    torch.rand(12 + 6, 2, generator=gen)
+    samples = torch.rand(256, 2, generator=gen) * 1.4 - 0.2
+    m = m.cuda()
+    with torch.no_grad():
+        m(samples.cuda(), update_grid=True)
+    sd = golden_state_dict(rec)
+    for l in range(2):
+        assert max_rel(m.layers[l].grid.cpu(), sd[f"layers.{l}.grid"]) <= 1e-5, l
+        assert max_rel(m.layers[l].spline_weight.cpu(), sd[f"layers.{l}.spline_weight"]) <= 2e-3, l
+    # and the step on the moved grid still matches the fixture's numbers
+    from pde_amd.pinn import BlackScholesStep
+    m.load_state_dict(sd)
+    x = torch.from_numpy(rec["x"]).cuda()
+    loss = BlackScholesStep(m)(x)
+    check(loss, rec, "loss")
