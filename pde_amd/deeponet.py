@@ -68,24 +68,33 @@ class PI_DeepONet(nn.Module):
         prod = self.brunk_net(u1, u2, u_s1, u_s2)
         return self.model4(prod.reshape(1, -1).float())
 
-    def operator_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
-        """run1.py:109-117: prediction at the n points, shape [n]."""
-        B = self.branch_row(u1, u2, u_s1, u_s2)
+    # the three evaluations below take the branch row B [1, p] as an argument so that one
+    # training step can share it between the boundary and the residual loss
+    def _predict(self, B, x, t) -> torch.Tensor:
         T = self.model5(self.helper(x, t))
         return torch.sum(B * T, dim=1)
 
-    def operator_jet(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
-        """(s, s_x, s_t, s_xx) at the n points, shape [n, 4]."""
-        B = self.branch_row(u1, u2, u_s1, u_s2)                       # [1, p]
+    def _jet(self, B, x, t) -> torch.Tensor:
         T = self.model5.forward_jet(self.helper(x, t))                # [n, p, 4]
         return torch.sum(B.unsqueeze(-1) * T, dim=1)
 
-    def residual_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
-        """run1.py:120-129."""
-        jet = self.operator_jet(u1, u2, u_s1, u_s2, x, t)
+    def _residual(self, B, x, t) -> torch.Tensor:
+        jet = self._jet(B, x, t)
         s, s_x, s_t, s_xx = jet[:, 0], jet[:, 1], jet[:, 2], jet[:, 3]
         x = self.reshape(x)
         return s_t - 0.5 * self.sigma ** 2 * x ** 2 * s_xx - self.rate * x * s_x + self.rate * s
+
+    def operator_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """run1.py:109-117: prediction at the n points, shape [n]."""
+        return self._predict(self.branch_row(u1, u2, u_s1, u_s2), x, t)
+
+    def operator_jet(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """(s, s_x, s_t, s_xx) at the n points, shape [n, 4]."""
+        return self._jet(self.branch_row(u1, u2, u_s1, u_s2), x, t)
+
+    def residual_net(self, u1, u2, u_s1, u_s2, x, t) -> torch.Tensor:
+        """run1.py:120-129."""
+        return self._residual(self.branch_row(u1, u2, u_s1, u_s2), x, t)
 
     def loss_bcs(self, u1, u2, u_s1, u_s2, x, t, output) -> torch.Tensor:
         """run1.py:134-141."""
@@ -103,8 +112,9 @@ class PI_DeepONet(nn.Module):
         x_i, t_i, outputs_i = bc_batch
         x_b, t_b, outputs_b = pde_batch
         optimizer.zero_grad()
-        bc_loss = self.loss_bcs(u1, u2, u_s1, u_s2, x_i, t_i, outputs_i)
-        pde_loss = self.loss_res(u1, u2, u_s1, u_s2, x_b, t_b, outputs_b)
+        B = self.branch_row(u1, u2, u_s1, u_s2)          # the same for both losses: evaluated once per step
+        bc_loss = torch.mean((outputs_i.flatten() - self._predict(B, x_i, t_i)) ** 2)
+        pde_loss = torch.mean((outputs_b.flatten() - self._residual(B, x_b, t_b)) ** 2)
         loss = pde_loss + self.bc_weight * bc_loss
         loss.backward()
         optimizer.step()
