@@ -70,6 +70,31 @@ def kernel_cost(name, widths, grid, n_pts, J):
     return flops, byts
 
 
+HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
+                 "fwd.sparse": "fwd_sparse_kernel<64, 4>", "head_fused": "head_bs_kernel<"}
+
+
+def profiled_traffic(kname, name, n_local):
+    """HBM bytes per launch of kernel `kname` from the committed rocprofv3 PMC summary
+    (2 x FETCH_SIZE + WRITE_SIZE, KB; FETCH_SIZE counts half the bytes of wide reads on gfx950).
+    The summary was taken on cfg2 at 2^20 points per GPU: only that workload gets a number."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.txt")
+    hip = HIP_KERNEL_OF.get(kname.split(".", 1)[1] if "." in kname else kname)
+    if name not in ("cfg2",) or n_local != (1 << 20) or hip is None or not os.path.exists(path):
+        return None
+    fetch = write = None
+    for line in open(path):
+        if line.startswith(hip.split("<")[0]) and hip in line:
+            for tok in line.split():
+                if tok.startswith("FETCH_SIZE="):
+                    fetch = float(tok.split("=")[1])
+                if tok.startswith("WRITE_SIZE="):
+                    write = float(tok.split("=")[1])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(name, model_sd, widths, act, steps=2):
     """The reference algorithm (dense Cox-de Boor + F.linear + nested autograd)
     on the host cores, on a bounded sample of the same workload."""
@@ -198,6 +223,10 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
                 "algorithmic_bytes_per_launch": kd["bytes"]}
+    roof["traffic"] = profiled_traffic(dom, name, n_local)
+    if roof["traffic"] is not None:
+        roof["traffic_source"] = "profiles/r01_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        roof["algorithmic_bytes_per_launch"] = kd["bytes"]
     step_flops = sum(k["flops"] * k["launches_per_step"] for k in kernels.values())
     kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
 

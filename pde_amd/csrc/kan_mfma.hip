@@ -220,7 +220,7 @@ template <int C1, int KIW, int PB>
 __global__ void __launch_bounds__(256, 2)
 bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
                        const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
-                       int64_t N, int I, int O, int act, int64_t chunk_pts) {
+                       int64_t N, int I, int O, int act, int64_t chunk_pts, int nx, int ny, int nz) {
   constexpr int COLS = KIW * C1;
   static_assert(COLS % 16 == 0, "16-wide column tiles");
   static_assert(PB * KIW <= 64, "one (point, feature) per lane");
@@ -235,17 +235,34 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
   float* sG = sE + 4 * COLS * RS;                        // [ROWS][RG]
   float* sK = sG + ROWS * RG;                            // [4*KIW][kKnotPad]
 
+  // 1-D launch, decoded so that the blocks which read the same gY rows (same point chunk and output
+  // tile, different feature groups) are 8 block ids apart: consecutive ids go round-robin over the 8 XCDs,
+  // so those blocks share one XCD's L2 and gY comes from HBM once.
+  int bx, by, bz;
+  {
+    const int b = blockIdx.x;
+    if (nz % 8 == 0) {
+      const int r = b >> 3;
+      bx = r % nx;
+      by = (r / nx) % ny;
+      bz = (r / (nx * ny)) * 8 + (b & 7);
+    } else {
+      bx = b % nx;
+      by = (b / nx) % ny;
+      bz = b / (nx * ny);
+    }
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p_local = lane % PB, f_local = lane / PB;
   const bool gen_lane = f_local < KIW;
-  const int i0 = (blockIdx.x * 4 + wave) * KIW;
-  const int o0 = blockIdx.y * 64;
+  const int i0 = (bx * 4 + wave) * KIW;
+  const int o0 = by * 64;
   float* tileE = sE + wave * COLS * RS;
   const int q = lane >> 4, l15 = lane & 15;
 
   for (int idx = tid; idx < 4 * KIW * (nk + 1); idx += 256) {
     const int f = idx / (nk + 1), k = idx - f * (nk + 1);
-    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, blockIdx.x * 4 * KIW + f, k, nk);
+    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, bx * 4 * KIW + f, k, nk);
   }
   if (gen_lane) zero_strip<C1>(tileE, RS, f_local, p_local);
   int prev_c0 = -100;
@@ -255,7 +272,7 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t pbeg = (int64_t)blockIdx.z * chunk_pts;
+  const int64_t pbeg = (int64_t)bz * chunk_pts;
   const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
 
   float4 greg[GV];
@@ -321,7 +338,7 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
   }
 #undef PDEKAN_BWW_FETCH
   // D[i = column][j = output]: this lane holds columns n*16 + 4q + reg of output m*16 + l15
-  float* dst0 = part + ((size_t)blockIdx.z * O + o0) * I * C1 + (size_t)i0 * C1;
+  float* dst0 = part + ((size_t)bz * O + o0) * I * C1 + (size_t)i0 * C1;
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -700,9 +717,10 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
   chunk = (chunk + PB - 1) / PB * PB;
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
   allow_big_lds(k, lds);
-  dim3 g(L.I / (4 * KIW), L.O / 64, nchunks);
-  k<<<g, 256, lds, st>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part,
-                         N, L.I, L.O, L.act, chunk);
+  const int nx = L.I / (4 * KIW), ny = L.O / 64;
+  k<<<(unsigned)(nx * ny * nchunks), 256, lds, st>>>(reinterpret_cast<const float4*>(a),
+                                                     reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part, N, L.I,
+                                                     L.O, L.act, chunk, nx, ny, nchunks);
 }
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
