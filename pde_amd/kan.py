@@ -28,6 +28,12 @@ from .spline_host import dense_bsplines, extended_knots, fit_coefficients
 __all__ = ["KANLinear", "KAN"]
 
 
+def _under_func_transform(t: torch.Tensor) -> bool:
+    """True while ``t`` is a torch.func wrapper (grad / vmap / jvp level)."""
+    fn = getattr(torch._C._functorch, "is_functorch_wrapped_tensor", None)
+    return bool(fn and fn(t))
+
+
 def _act_kind(module: torch.nn.Module) -> Optional[int]:
     """Kernel id of a base activation, or None when the kernels do not know it."""
     if type(module) is torch.nn.Identity:
@@ -109,6 +115,15 @@ class KANLinear(torch.nn.Module):
         flat = x.reshape(-1, self.in_features)
         kind = _act_kind(self.base_activation)
         grid, bw, sw, sc = self._kernel_params()
+        if _under_func_transform(flat):
+            # torch.func transforms (the scripts' jacrev / hessian, run1.py:122-124) trace through tensor ops and
+            # cannot see inside a library call: under them the layer is its defining expression (kan.py:153-166)
+            # in differentiable tensor ops on whatever device the input lives on.  O(n^2)/O(n^3) like the scripts;
+            # forward_jet gives the same derivatives in O(n).
+            base = F.linear(self.base_activation(flat), bw)
+            spline = F.linear(dense_bsplines(flat, grid, self.spline_order).view(flat.size(0), -1),
+                              self.scaled_spline_weight.view(self.out_features, -1))
+            return (base + spline).view(*lead, self.out_features)
         if kind is not None:
             out = K.kan_layer(flat, grid, bw, sw, sc, kind, self.grid_size, self.spline_order)
         else:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden_state_dict
+from conftest import ROOT, golden_state_dict, max_rel
 
 
 def test_library_exports_every_declared_symbol():
@@ -152,3 +152,31 @@ def test_install_as_efficient_kan():
         for k in [k for k in sys.modules if k.startswith("efficient_kan")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_jacrev_hessian_through_forward_match_reference(golden):
+    """The scripts differentiate through `forward` with torch.func.jacrev / hessian
+    (run1.py:121-124).  Under those transforms the layer evaluates its defining
+    expression in tensor ops, so the unmodified calls work; the numbers are the
+    fixture's (made with the reference's KAN)."""
+    from torch.func import hessian, jacrev
+    from pde_amd import KAN
+    rec = golden("jacrev_hessian")
+    m = KAN([2, 6, 1], grid_size=5, base_activation=torch.nn.Identity)
+    m.load_state_dict(golden_state_dict(rec))
+    x = torch.from_numpy(rec["x"][:, 0].copy())
+    t = torch.from_numpy(rec["x"][:, 1].copy())
+
+    def net(xx, tt):
+        return m(torch.stack([xx.reshape(-1), tt.reshape(-1)]).permute(1, 0))[:, 0]
+
+    s_x = jacrev(net, argnums=0)(x, t).sum(dim=0)
+    s_xx = hessian(net, argnums=0)(x, t).sum(dim=0).sum(dim=0)
+    s_t = jacrev(net, argnums=1)(x, t).sum(dim=0)
+    assert max_rel(s_x, rec["s_x"]) <= 1e-5
+    assert max_rel(s_xx, rec["s_xx"]) <= 1e-5
+    assert max_rel(s_t, rec["s_t"]) <= 1e-5
+    # outside a transform a CPU tensor is still refused: the hot path has no CPU implementation
+    import pytest
+    with pytest.raises(RuntimeError):
+        net(x, t)

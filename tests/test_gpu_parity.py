@@ -421,3 +421,27 @@ def test_update_grid_on_device_matches_reference_fixture(golden):
     x = torch.from_numpy(rec["x"]).cuda()
     loss = BlackScholesStep(m)(x)
     check(loss, rec, "loss")
+
+
+def test_jacrev_hessian_callers_work_on_the_gpu(golden):
+    """run1.py:121-124 as written (jacrev / hessian through `forward`) on a GPU model:
+    same numbers as the fixture and as the O(n) jets."""
+    from torch.func import hessian, jacrev
+    rec = golden("jacrev_hessian")
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"][:, 0].copy()).cuda()
+    t = torch.from_numpy(rec["x"][:, 1].copy()).cuda()
+
+    def net(xx, tt):
+        return m(torch.stack([xx.reshape(-1), tt.reshape(-1)]).permute(1, 0))[:, 0]
+
+    s = net(x, t)                                        # the kernels
+    s_x = jacrev(net, argnums=0)(x, t).sum(dim=0)        # tensor ops under the transform
+    s_xx = hessian(net, argnums=0)(x, t).sum(dim=0).sum(dim=0)
+    s_t = jacrev(net, argnums=1)(x, t).sum(dim=0)
+    for val, key in ((s, "s"), (s_x, "s_x"), (s_xx, "s_xx"), (s_t, "s_t")):
+        assert max_rel(val.detach().cpu(), rec[key]) <= TOL, key
+    jet = m.forward_jet(torch.stack([x, t], 1))[:, 0, :]
+    assert max_rel(jet[:, 1].cpu(), s_x.cpu()) <= TOL
+    assert max_rel(jet[:, 2].cpu(), s_t.cpu()) <= TOL
+    assert max_rel(jet[:, 3].cpu(), s_xx.cpu()) <= TOL
