@@ -88,6 +88,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=100, help="run1.py:470-471")
     ap.add_argument("--epochs", type=int, default=20, help="the script trains 1500 (run1.py:211)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one training step in a HIP graph and replay it (the step is ~100 short launches)")
     args = ap.parse_args(argv)
 
     from pde_amd import KAN
@@ -106,13 +108,43 @@ def main(argv=None):
                      generator=gen)
     dl2 = DataLoader(TensorDataset(data["x_b"], data["t_b"], data["outputs_b"]), batch_size=args.batch, shuffle=True,
                      generator=gen)
-    opt = torch.optim.AdamW(net.parameters(), lr=0.01)                 # run1.py:209
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01, capturable=args.graph)   # run1.py:209
     u_s1, u_s2 = data["u_1"][:, 2], data["u_2"][:, 2]
+
+    step_fn = lambda bc, pde: net.train_step(opt, data["u_1"], data["u_2"], u_s1, u_s2, bc, pde)
+    if args.graph:
+        # static batch buffers + one captured step; batches are copied in, the graph is replayed
+        nb = min(args.batch, args.P, args.Q)
+        sbc = [torch.zeros(nb, device=dev) for _ in range(3)]
+        spde = [torch.zeros(nb, device=dev) for _ in range(3)]
+        first_bc, first_pde = next(iter(dl1)), next(iter(dl2))
+        for dst, src in zip(sbc + spde, list(first_bc) + list(first_pde)):
+            dst.copy_(src[:nb])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, lazy inits)
+            for _ in range(3):
+                step_fn(sbc, spde)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = step_fn(sbc, spde)
+
+        def step_fn(bc, pde):                              # noqa: F811  (replaces the eager step)
+            if bc[0].numel() != nb or pde[0].numel() != nb:
+                return None                                # a ragged last batch is skipped in graph mode
+            for dst, src in zip(sbc + spde, list(bc) + list(pde)):
+                dst.copy_(src)
+            graph.replay()
+            return captured
+
     t0 = time.time()
     history = []
     for epoch in range(args.epochs):
         for bc_batch, pde_batch in zip(dl1, dl2):
-            loss, pde_loss, bc_loss = net.train_step(opt, data["u_1"], data["u_2"], u_s1, u_s2, bc_batch, pde_batch)
+            out = step_fn(bc_batch, pde_batch)
+            if out is not None:
+                loss, pde_loss, bc_loss = out
         history.append((float(pde_loss), float(bc_loss)))
         print(f"epoch {epoch:4d}  pde loss {history[-1][0]:.3e} | bc loss {history[-1][1]:.3e}", flush=True)
     torch.cuda.synchronize()

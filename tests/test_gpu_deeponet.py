@@ -88,16 +88,19 @@ def test_column_inputs_and_strided_points(golden):
     assert torch.equal(j[:, 0], a)
 
 
-def test_example_training_run_learns():
+@pytest.mark.parametrize("graph", [False, True])
+def test_example_training_run_learns(graph):
     """examples/run1_pi_deeponet.py end to end at a reduced size: finite losses,
-    and the boundary loss falls over the epochs."""
+    and the boundary loss falls over the epochs; eagerly and with the step
+    captured in a HIP graph and replayed."""
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run1_pi_deeponet.py")
     spec = importlib.util.spec_from_file_location("run1_pi_deeponet", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out = mod.main(["--P", "300", "--Q", "200", "--batch", "100", "--epochs", "12", "--seed", "0"])
+    out = mod.main(["--P", "300", "--Q", "200", "--batch", "100", "--epochs", "12", "--seed", "0"] +
+                   (["--graph"] if graph else []))
     hist = torch.tensor(out["history"])
     assert torch.isfinite(hist).all()
     assert hist[-3:, 1].mean() < hist[:3, 1].mean()
