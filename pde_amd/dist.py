@@ -32,18 +32,23 @@ def shard_points(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 class FlatAllReduce:
     """Sum ``flat_grad`` and ``loss`` over the ranks with a single collective."""
 
-    def __init__(self, flat_grad: torch.Tensor, dist_module):
+    def __init__(self, flat_grad: torch.Tensor, dist_module, grad_and_loss: Optional[torch.Tensor] = None):
         self.dist = dist_module
         self.flat_grad = flat_grad
-        # one message: gradients followed by the loss
-        self.buf = torch.zeros(flat_grad.numel() + 1, dtype=flat_grad.dtype, device=flat_grad.device)
+        # one message: gradients followed by the loss.  A step that already keeps both in one buffer
+        # (`grad_and_loss`, gradients first) is reduced in place; otherwise they are gathered into a copy.
+        self.in_place = grad_and_loss is not None
+        self.buf = grad_and_loss if self.in_place else torch.zeros(flat_grad.numel() + 1, dtype=flat_grad.dtype,
+                                                                    device=flat_grad.device)
 
     def __call__(self, loss: torch.Tensor) -> torch.Tensor:
         n = self.flat_grad.numel()
-        self.buf[:n].copy_(self.flat_grad)
-        self.buf[n:].copy_(loss.reshape(1))
+        if not self.in_place:
+            self.buf[:n].copy_(self.flat_grad)
+            self.buf[n:].copy_(loss.reshape(1))
         self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
-        self.flat_grad.copy_(self.buf[:n])
+        if not self.in_place:
+            self.flat_grad.copy_(self.buf[:n])
         return self.buf[n]
 
 
@@ -53,7 +58,7 @@ class DataParallelStep:
 
     def __init__(self, step, dist_module):
         self.step = step
-        self.reduce = FlatAllReduce(step.flat_grad, dist_module)
+        self.reduce = FlatAllReduce(step.flat_grad, dist_module, getattr(step, "grad_and_loss", None))
 
     def __call__(self, x_shard: torch.Tensor, n_global: int, target: Optional[torch.Tensor] = None) -> torch.Tensor:
         loss = self.step(x_shard, target=target, n_global=n_global)

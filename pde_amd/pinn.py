@@ -49,7 +49,9 @@ class BlackScholesStep:
         if model.layers[-1].out_features != 1:
             raise ValueError("the PINN head must have one output")
         total = sum(p.numel() for p in params)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # gradients and the loss share one buffer so that a data-parallel wrapper can all-reduce both in place
+        self.grad_and_loss = torch.zeros(total + 1, dtype=torch.float32, device=self.device)
+        self.flat_grad = self.grad_and_loss[:total]
         self._views: List[torch.Tensor] = []
         off = 0
         for p in params:
@@ -57,7 +59,7 @@ class BlackScholesStep:
             off += p.numel()
             p.grad = v
             self._views.append(v)
-        self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        self.loss = self.grad_and_loss[total]              # 0-d view of the last element
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = None
 
