@@ -445,3 +445,20 @@ def test_jacrev_hessian_callers_work_on_the_gpu(golden):
     assert max_rel(jet[:, 1].cpu(), s_x.cpu()) <= TOL
     assert max_rel(jet[:, 2].cpu(), s_t.cpu()) <= TOL
     assert max_rel(jet[:, 3].cpu(), s_xx.cpu()) <= TOL
+
+
+@pytest.mark.parametrize("widths,G", [([2, 64, 64, 1], 10), ([2, 64, 128, 64, 1], 10), ([2, 64, 64, 1], 20)])
+def test_fused_step_is_bitwise_reproducible(widths, G):
+    """No float atomics anywhere and fixed-order reductions: identical inputs give
+    bit-identical loss and gradients, at a size where every CU holds several
+    workgroups of every kernel."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, G, 77).cuda()
+    x = torch.rand(1 << 18, 2, generator=torch.Generator().manual_seed(9)).cuda()
+    step = BlackScholesStep(m)
+    l0 = step(x).clone()
+    g0 = step.flat_grad.clone()
+    for _ in range(3):
+        l1 = step(x)
+        assert torch.equal(l1, l0)
+        assert torch.equal(step.flat_grad, g0)
