@@ -9,7 +9,7 @@ libpdekan.so), + gradient all-reduce over RCCL when N > 1, + an AdamW update.
 Points and weights are synthetic (seeded), resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-Workloads (BASELINE.json configs):
+Workloads:
   cfg1  KAN [2,5,1]            grid 5   10^4 points
   cfg2  KAN [2,64,64,1]        grid 10  2^20 points per GPU   (default at --gpus 1)
   cfg3  = cfg2 sharded, 2^24 points over 8 GPUs -> 2^21 per GPU (default at --gpus > 1)
