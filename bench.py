@@ -229,6 +229,8 @@ def main():
         roof["algorithmic_bytes_per_launch"] = kd["bytes"]
     step_flops = sum(k["flops"] * k["launches_per_step"] for k in kernels.values())
     kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
+    step_roof_ms = 1e3 * sum(k["launches_per_step"] * max(k["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                                                          k["bytes"] / (PEAK_HBM_GBS * 1e9)) for k in kernels.values())
 
     out = {
         "metric": "collocation pts/s per KAN-PINN train step",
@@ -242,6 +244,9 @@ def main():
         "loss": loss_val,
         "roofline": roof,
         "step_dense_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+        # whole-step roofline: sum over the kernels of max(dense flops / fp32 peak, algorithmic bytes / HBM peak)
+        "step_roofline_ms": step_roof_ms,
+        "step_roofline_frac": step_roof_ms / ms_per_step,
         "kernel_ms_per_step": kernel_ms,
         "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
                     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
