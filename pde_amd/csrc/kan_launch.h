@@ -67,7 +67,9 @@ void launch_bwd_weight_mfma_skinny(const LayerView& L, const float* a, const flo
 void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st);
 void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
                            int64_t N, hipStream_t st);
+// with_bf16x3: feature blocks with equally spaced knots go to the split-bf16 kernel, the rest stay fp32
+bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N);
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
-                            int64_t N, hipStream_t st);
+                            int64_t N, hipStream_t st, bool with_bf16x3 = false);
 
 }  // namespace pdekan

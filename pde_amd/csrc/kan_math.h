@@ -63,8 +63,7 @@ template <typename KnotPtr>
 KAN_HD int find_interval(const KnotPtr g, int nk, float x) {
   const float g0 = g[0], g1 = g[nk - 1];
   float u = (x - g0) * kan_rcp(g1 - g0) * (float)(nk - 1);
-  int s = (u > 0.0f) ? (int)u : 0;          // NaN -> 0
-  if (s > nk - 2) s = nk - 2;
+  int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;   // NaN -> 0; clamped before the conversion
   while (s > 0 && x < g[s]) --s;
   while (s < nk - 2 && x >= g[s + 1]) ++s;
   return s;
@@ -130,18 +129,9 @@ KAN_HD void eval_basis(const KnotPtr g, int nk, float x, Basis& out) {
 // t = (x - g_s) / h in [0,1) the four live cubic bases are fixed polynomials,
 //   N0 = (1-t)^3/6, N1 = (3t^3-6t^2+4)/6, N2 = (-3t^3+3t^2+3t+1)/6, N3 = t^3/6,
 // and each derivative order brings one factor 1/h.  No reciprocals, 2 knot reads.
-template <bool kNeedD3, typename KnotPtr>
-KAN_HD void eval_basis_uniform(const KnotPtr g, int nk, float inv_h, float x, Basis& out) {
-  const float g0 = g[0];
-  float u = (x - g0) * inv_h;
-  int s = (u > 0.0f) ? (int)u : 0;
-  if (s > nk - 2) s = nk - 2;
-  while (s > 0 && x < g[s]) --s;            // rounding at a knot: at most one step
-  while (s < nk - 2 && x >= g[s + 1]) ++s;
-  out.c0 = s - kOrder;
-  out.inside = (x >= g0) && (x < g[nk - 1]);
-  const float m = out.inside ? 1.0f : 0.0f;
-  const float t = out.inside ? (x - g[s]) * inv_h : 0.0f;
+template <bool kNeedD3>
+KAN_HD void uniform_cubic_pieces(float t, bool inside, float inv_h, Basis& out) {
+  const float m = inside ? 1.0f : 0.0f;
   const float t2 = t * t, t3 = t2 * t, q = 1.0f - t;
   const float sixth = 1.0f / 6.0f;
   out.b[0] = m * (q * q * q * sixth);
@@ -164,6 +154,38 @@ KAN_HD void eval_basis_uniform(const KnotPtr g, int nk, float inv_h, float x, Ba
   } else {
     out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
   }
+}
+
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis_uniform(const KnotPtr g, int nk, float inv_h, float x, Basis& out) {
+  const float g0 = g[0];
+  float u = (x - g0) * inv_h;
+  int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;   // NaN -> 0; clamped before the conversion
+  while (s > 0 && x < g[s]) --s;            // rounding at a knot: at most one step
+  while (s < nk - 2 && x >= g[s + 1]) ++s;
+  out.c0 = s - kOrder;
+  out.inside = (x >= g0) && (x < g[nk - 1]);
+  const float t = out.inside ? (x - g[s]) * inv_h : 0.0f;
+  uniform_cubic_pieces<kNeedD3>(t, out.inside, inv_h, out);
+}
+
+// The same without a loop or branch (selects only), for code that must stay one
+// basic block: the two rounding corrections above never take more than one step
+// each when the knots are equally spaced.
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis_uniform_straight(const KnotPtr g, int nk, float inv_h, float x, Basis& out) {
+  const float g0 = g[0], glast = g[nk - 1];
+  const float u = (x - g0) * inv_h;
+  int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
+  const float ga = g[s];                     // every knot read is unconditional: no short-circuit branches
+  s -= (int)(s > 0) & (int)(x < ga);
+  const float gb = g[s + 1];
+  s += (int)(s < nk - 2) & (int)(x >= gb);
+  const float gs = g[s];
+  out.c0 = s - kOrder;
+  out.inside = (int)(x >= g0) & (int)(x < glast);
+  const float t = out.inside ? (x - gs) * inv_h : 0.0f;
+  uniform_cubic_pieces<kNeedD3>(t, out.inside, inv_h, out);
 }
 
 // 1/h when the nk knots are equally spaced to within 1e-6*h, else 0.  The default

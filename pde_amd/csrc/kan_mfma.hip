@@ -220,7 +220,7 @@ template <int C1, int KIW, int PB>
 __global__ void __launch_bounds__(256, 2)
 bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
                        const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
-                       int64_t N, int I, int O, int act, int64_t chunk_pts, int nx, int ny, int nz) {
+                       int64_t N, int I, int O, int act, int64_t chunk_pts, int nx, int ny, int nz, int skip_uniform) {
   constexpr int COLS = KIW * C1;
   static_assert(COLS % 16 == 0, "16-wide column tiles");
   static_assert(PB * KIW <= 64, "one (point, feature) per lane");
@@ -253,6 +253,8 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
     }
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // blocks whose features all have equally spaced knots belong to bwd_weight_bf16x3_kernel when it runs too
+  if (skip_uniform && __builtin_amdgcn_ballot_w64(ginfo[bx * 4 * KIW + lane % (4 * KIW)] != 0.0f) == ~0ull) return;
   const int p_local = lane % PB, f_local = lane / PB;
   const bool gen_lane = f_local < KIW;
   const int i0 = (bx * 4 + wave) * KIW;
@@ -346,6 +348,308 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
       float* dst = dst0 + (size_t)(m * 16 + l15) * I * C1 + n * 16 + 4 * q;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) dst[rg] = acc[n][m][rg];
+    }
+}
+
+// ==========================================================================
+// weight gradients on the bf16 matrix cores with fp32 accuracy, for feature
+// blocks whose knots are equally spaced (1/h known per feature).
+//
+// Every fp32 operand x is cut into three bf16 pieces hi + mid + lo by
+// truncation (hi = the top 8 significant bits, mid the next 8, lo the last 8:
+// the remainders are exact fp32 subtractions, so hi + mid + lo == x exactly)
+// and a product a*b is taken as
+//     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi,
+// six v_mfma_f32_16x16x32_bf16 whose bf16 x bf16 products are exact in the fp32
+// accumulator.  The terms left out are below 2^-21 |a b| (2^-23 on average), the
+// order of an fp32 product's own rounding, and the matrix work costs 6/16 of
+// the fp32-MFMA time.
+//
+// Every wave is on its own (no block barrier): wave = 8 features x C1 columns
+// (NT = 8*C1/16 column tiles) x 64 outputs of accumulators over a chunk of
+// points, walked 8 points (K = 8 x 4 jets = 32 = one MFMA) at a time.  One wave
+// per SIMD, so the instruction stream itself is software-pipelined: the vector
+// work that prepares step s+1 sits between the matrix instructions of step s.
+//   B operand (gY): lane (r = lane&15, q = lane>>4) holds output 16m + r, jets of
+//     points 2q and 2q+1: two 16-byte loads per output tile, fetched two steps
+//     ahead into registers, cut into planes at the start of their step.
+//   A operand (E^T): lane (p = lane&7, f = lane>>3) expands its (point,
+//     feature) pair (the 4 live spline columns + the base column), cuts the 20
+//     jets into planes and parks them in the wave's own LDS tile
+//     [3 planes][8*C1 columns][32 bf16 + pad]; the 4 columns it wrote one step
+//     earlier are cleared, everything else of the tile stays zero.  The tile is
+//     read back in MFMA operand order (ds_read_b128).  LDS operations of a
+//     wave complete in order, so the tile of step s+1 is written right after
+//     the last operand read of step s has been issued.
+// A block (4 waves = 32 features) returns at once unless all its 32 features have
+// equally spaced knots; bwd_weight_mfma_kernel, launched with skip_uniform = 1
+// on the same grid, then does exactly the blocks this kernel leaves out.
+// Output: part[chunk][O][I][C1].
+// ==========================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (x0, x1) -> one dword of each of the three bf16 planes, x0 in the low half
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  constexpr unsigned kHiHalves = 0x07060302u;            // v_perm_b32: {S0.hi16, S1.hi16}
+  const unsigned a0 = __float_as_uint(x0), a1 = __float_as_uint(x1);
+  h = __builtin_amdgcn_perm(a1, a0, kHiHalves);
+  const float r0 = x0 - __uint_as_float(a0 & 0xffff0000u), r1 = x1 - __uint_as_float(a1 & 0xffff0000u);
+  const unsigned b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+  m = __builtin_amdgcn_perm(b1, b0, kHiHalves);
+  const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), kHiHalves);
+}
+
+struct Planes2 { u32x2 h, m, l; };                         // the 4 jets of one scalar
+struct GyPlanes { u32x4 h[4], m[4], l[4]; };               // 4 output tiles x (2 points x 4 jets)
+
+__device__ __forceinline__ Planes2 split_jet(float4 v) {
+  Planes2 r;
+  unsigned h0, m0, l0, h1, m1, l1;
+  split_pair(v.x, v.y, h0, m0, l0);
+  split_pair(v.z, v.w, h1, m1, l1);
+  r.h = (u32x2){h0, h1}; r.m = (u32x2){m0, m1}; r.l = (u32x2){l0, l1};
+  return r;
+}
+
+__device__ __forceinline__ void split_gy(const float4 (&g)[4][2], GyPlanes& G) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const Planes2 p0 = split_jet(g[m][0]), p1 = split_jet(g[m][1]);
+    G.h[m] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
+    G.m[m] = (u32x4){p0.m.x, p0.m.y, p1.m.x, p1.m.y};
+    G.l[m] = (u32x4){p0.l.x, p0.l.y, p1.l.x, p1.l.y};
+  }
+}
+
+__device__ __forceinline__ void split_gy_tile(const float4 (&g)[2], GyPlanes& G, int m) {
+  const Planes2 p0 = split_jet(g[0]), p1 = split_jet(g[1]);
+  G.h[m] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
+  G.m[m] = (u32x4){p0.m.x, p0.m.y, p1.m.x, p1.m.y};
+  G.l[m] = (u32x4){p0.l.x, p0.l.y, p1.l.x, p1.l.y};
+}
+
+// the expanded jets of one (point, feature) pair: 4 live spline columns c0..c0+3 and the base column
+struct PairJets { float4 col[5]; int c0; };
+struct PairPlanes { Planes2 col[5]; };
+
+template <int ACT>
+__device__ __forceinline__ void expand_pair(const float* knots, int nk, float4 jet, PairJets& out) {
+  Basis bs;
+  eval_basis_uniform_straight<false>(knots, nk, knots[nk], jet.x, bs);
+  const Act av = eval_act(ACT, jet.x);
+  const float s2 = jet.y * jet.y;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    out.col[m] = make_float4(bs.b[m], bs.d1[m] * jet.y, bs.d1[m] * jet.z, bs.d2[m] * s2 + bs.d1[m] * jet.w);
+  out.col[4] = make_float4(av.f0, av.f1 * jet.y, av.f1 * jet.z, av.f2 * s2 + av.f1 * jet.w);
+  out.c0 = bs.c0;
+}
+
+// park a pair's planes in the wave's E tile: clear the columns written one step earlier, write the live ones
+template <int C1, int COLS, int RW>
+__device__ __forceinline__ void park_pair(unsigned* base, unsigned* dump, const PairPlanes& pp, int c0, int& prev_c0) {
+  constexpr int C = C1 - 1, PL = COLS * RW;
+  const u32x2 zero = {0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = prev_c0 + m;
+    unsigned* dst = (c >= 0 && c < C) ? base + c * RW : dump;
+    *reinterpret_cast<u32x2*>(dst) = zero;
+    *reinterpret_cast<u32x2*>(dst + PL) = zero;
+    *reinterpret_cast<u32x2*>(dst + 2 * PL) = zero;
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = (m < 4) ? c0 + m : C;
+    unsigned* dst = (m == 4 || (c >= 0 && c < C)) ? base + c * RW : dump;
+    *reinterpret_cast<u32x2*>(dst) = pp.col[m].h;
+    *reinterpret_cast<u32x2*>(dst + PL) = pp.col[m].m;
+    *reinterpret_cast<u32x2*>(dst + 2 * PL) = pp.col[m].l;
+  }
+  prev_c0 = c0;
+}
+
+struct TileOps { u32x4 h, m, l; };
+
+template <int COLS, int RW>
+__device__ __forceinline__ TileOps read_tile(const unsigned* esrc, int t) {
+  TileOps o;
+  o.h = *reinterpret_cast<const u32x4*>(esrc + t * 16 * RW);
+  o.m = *reinterpret_cast<const u32x4*>(esrc + t * 16 * RW + COLS * RW);
+  o.l = *reinterpret_cast<const u32x4*>(esrc + t * 16 * RW + 2 * COLS * RW);
+  return o;
+}
+
+__device__ __forceinline__ void mfma_tile(f32x4 (&acc)[4], const TileOps& e, const GyPlanes& G) {
+  const bf16x8 eh = __builtin_bit_cast(bf16x8, e.h), em = __builtin_bit_cast(bf16x8, e.m),
+               el = __builtin_bit_cast(bf16x8, e.l);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, G.h[m]), bm = __builtin_bit_cast(bf16x8, G.m[m]),
+                 bl = __builtin_bit_cast(bf16x8, G.l[m]);
+    f32x4 c = acc[m];                        // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, bh, c, 0, 0, 0);
+    acc[m] = c;
+  }
+}
+
+// 16 bytes at a wave-uniform row address plus a 32-bit per-lane byte offset (scalar base + vector offset load)
+__device__ __forceinline__ float4 ld16(const char* __restrict__ row, unsigned off) {
+  return *reinterpret_cast<const float4*>(row + off);
+}
+
+constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 16 bytes of pad (bank spread; dump slot)
+
+// One step = 8 points = NT = 7 regions of 24 matrix instructions (one column tile each), fenced so that each
+// region keeps its own share of the vector work that prepares step s+1 (one wave per SIMD: nothing else would
+// fill the matrix instructions' issue gaps).  graw / xraw hold the raw rows of step s+1 on entry; each piece is
+// fetched again (rows of step s+2, at pnext2) right after the region that consumed it:
+//   region 0        evaluate the basis of the pairs of step s+1 (xraw); fetch gY tile 3 of step s+1 (pnext1)
+//   region 1        fetch xraw of step s+2
+//   regions 1..3    cut the pairs' 5 columns into planes
+//   regions 3..6    cut gY tile 0..3 of step s+1 into planes (Gn); regions 4..6 fetch tiles 0..2 of step s+2
+//   region 5        park the pairs' planes (every operand read of the E tile of step s has been issued by then)
+//   region 6        read the first operands of step s+1
+template <int C1, int ACT>
+__device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const GyPlanes& G, GyPlanes& Gn, TileOps& cur,
+                                            float4 (&graw)[4][2], float4& xraw, unsigned* sE, const float* knots,
+                                            int& prev_c0, const char* __restrict__ xrow2, const char* __restrict__ grow1,
+                                            const char* __restrict__ grow2, unsigned xoff, unsigned goff, int lane,
+                                            int O) {
+  constexpr int COLS = 8 * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
+  static_assert(NT == 7, "the region plan below is written for 7 column tiles");
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = lane >> 3;
+  const unsigned* esrc = sE + r * RW + q * 4;
+  PairJets pj;
+  PairPlanes pp;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    TileOps nxt;
+    if (t + 1 < NT) nxt = read_tile<COLS, RW>(esrc, t + 1);
+    if (t == 0) {
+      expand_pair<ACT>(knots, nk, xraw, pj);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) graw[3][e] = ld16(grow1, goff + (unsigned)(e * O + 3 * 16) * 16u);
+    }
+    if (t == 1) xraw = ld16(xrow2, xoff);
+    if (t == 1) { pp.col[0] = split_jet(pj.col[0]); pp.col[1] = split_jet(pj.col[1]); }
+    if (t == 2) { pp.col[2] = split_jet(pj.col[2]); pp.col[3] = split_jet(pj.col[3]); }
+    if (t == 3) pp.col[4] = split_jet(pj.col[4]);
+    if (t >= 3) split_gy_tile(graw[t - 3], Gn, t - 3);
+    if (t >= 4) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) graw[t - 4][e] = ld16(grow2, goff + (unsigned)(e * O + (t - 4) * 16) * 16u);
+    }
+    if (t == 5) {
+      unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
+      park_pair<C1, COLS, RW>(base, sE + (f_local * C1) * RW + 16, pp, pj.c0, prev_c0);
+    }
+    if (t == 6) nxt = read_tile<COLS, RW>(esrc, 0);
+    mfma_tile(acc[t], cur, G);
+    cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int C1, int ACT>
+__global__ void __launch_bounds__(256, 1)
+bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
+                         const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
+                         int64_t N, int I, int O, int64_t chunk_pts, int nx, int ny, int nz) {
+  constexpr int COLS = 8 * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
+  static_assert(COLS % 16 == 0, "16-wide column tiles");
+  constexpr int kWaveWords = 3 * COLS * RW + 8 * kKnotPad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bx, by, bz;                            // same decode as bwd_weight_mfma_kernel
+  {
+    const int b = blockIdx.x;
+    if (nz % 8 == 0) {
+      const int rr = b >> 3;
+      bx = rr % nx; by = (rr / nx) % ny; bz = (rr / (nx * ny)) * 8 + (b & 7);
+    } else {
+      bx = b % nx; by = (b / nx) % ny; bz = b / (nx * ny);
+    }
+  }
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (__builtin_amdgcn_ballot_w64(ginfo[bx * 32 + (lane & 31)] != 0.0f) != ~0ull) return;
+
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;   // this wave's tile: [3][COLS][RW]
+  float* sK = reinterpret_cast<float*>(sE + 3 * COLS * RW);               // and its 8 knot rows
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = lane >> 3;
+  const int i0 = (bx * 4 + wave) * 8, o0 = by * 64;
+  for (int idx = lane; idx < 8 * (nk + 1); idx += 64) {
+    const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, i0 + f, k, nk);
+  }
+  for (int idx = lane; idx < 3 * COLS * RW; idx += 64) sE[idx] = 0u;
+  const float* knots = sK + f_local * kKnotPad;
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // N and chunk_pts are multiples of 16: whole pairs of steps
+  const int64_t pbeg = (int64_t)bz * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  // rows are addressed as (wave-uniform row pointer) + (32-bit lane offset)
+  const char* xb = reinterpret_cast<const char*>(a);
+  const char* gb = reinterpret_cast<const char*>(gy);
+  const unsigned xoff = (unsigned)(p_local * I + i0 + f_local) * 16u;
+  const unsigned goff = (unsigned)(2 * q * O + o0 + r) * 16u;
+  const size_t xstride = (size_t)I * 16, gstride = (size_t)O * 16;       // bytes per point
+
+  if (pbeg < pend) {
+    float4 graw[4][2], xraw;
+    GyPlanes GA, GB;
+    int prev_c0 = -100;
+    {
+      float4 g0[4][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          g0[m][e] = ld16(gb + pbeg * gstride, goff + (unsigned)(e * O + m * 16) * 16u);
+          graw[m][e] = ld16(gb + (pbeg + 8) * gstride, goff + (unsigned)(e * O + m * 16) * 16u);
+        }
+      const float4 x0 = ld16(xb + pbeg * xstride, xoff);
+      xraw = ld16(xb + (pbeg + 8) * xstride, xoff);
+      PairJets pj;
+      PairPlanes pp;
+      expand_pair<ACT>(knots, nk, x0, pj);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) pp.col[m] = split_jet(pj.col[m]);
+      unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
+      park_pair<C1, COLS, RW>(base, sE + (f_local * C1) * RW + 16, pp, pj.c0, prev_c0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) split_gy_tile(g0[m], GA, m);
+    }
+    TileOps cur = read_tile<COLS, RW>(sE + r * RW + q * 4, 0);
+    for (int64_t pb = pbeg; pb < pend; pb += 16) {
+      // past the end of the chunk: any valid rows, fetched (and expanded) but never used
+      const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
+      bf16x3_step<C1, ACT>(acc, GA, GB, cur, graw, xraw, sE, knots, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
+                           gb + p2 * gstride, xoff, goff, lane, O);
+      bf16x3_step<C1, ACT>(acc, GB, GA, cur, graw, xraw, sE, knots, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
+                           gb + p3 * gstride, xoff, goff, lane, O);
+    }
+  }
+  // D[row][output]: this lane holds columns 16t + 4q .. + 3 of output 16m + r
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float* dst = part + (((size_t)bz * O + o0 + m * 16 + r) * I + i0) * C1 + t * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(dst) = acc[t][m];
     }
 }
 
@@ -708,24 +1012,42 @@ void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float*
   else fwd_launch<9, 4>(L, a, wt, y, N, st);
 }
 
+// split-bf16 weight gradients: grid 10 (8 features x 14 columns = 7 column tiles), whole pairs of 8-point steps
+bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N) {
+  if (!mfma_eligible(D, D2, L) || L.G != 10 || N % 16 != 0 || !L.ginfo) return false;
+  const char* off = getenv("PDEKAN_DISABLE_BF16X3");    // A/B switch for tests and profiling
+  return !(off && off[0] == '1');
+}
+
 template <int C1, int KIW, int PB>
 static void bww_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
-                       hipStream_t st) {
+                       hipStream_t st, bool with_bf16x3 = false) {
   constexpr int COLS = KIW * C1, ROWS = PB * 4, RS = ROWS + 4;
   const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
   int64_t chunk = (N + nchunks - 1) / nchunks;
-  chunk = (chunk + PB - 1) / PB * PB;
+  const int step_pts = with_bf16x3 ? 16 : PB;            // the split-bf16 kernel walks pairs of 8-point steps
+  chunk = (chunk + step_pts - 1) / step_pts * step_pts;
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
   allow_big_lds(k, lds);
   const int nx = L.I / (4 * KIW), ny = L.O / 64;
   k<<<(unsigned)(nx * ny * nchunks), 256, lds, st>>>(reinterpret_cast<const float4*>(a),
                                                      reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part, N, L.I,
-                                                     L.O, L.act, chunk, nx, ny, nchunks);
+                                                     L.O, L.act, chunk, nx, ny, nchunks, with_bf16x3 ? 1 : 0);
+  if constexpr (C1 % 2 == 0 && KIW == 8 && PB == 8) {
+    if (with_bf16x3) {                                   // the blocks the launch above skipped
+      auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, kActSiLU> : bwd_weight_bf16x3_kernel<C1, kActIdentity>;
+      const size_t lds_b = (size_t)4 * (3 * 8 * C1 * kBf16Rw + 8 * kKnotPad) * 4;
+      allow_big_lds(kb, lds_b);
+      kb<<<(unsigned)(nx * ny * nchunks), 256, lds_b, st>>>(reinterpret_cast<const float4*>(a),
+                                                            reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part,
+                                                            N, L.I, L.O, chunk, nx, ny, nchunks);
+    }
+  }
 }
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
-                            hipStream_t st) {
-  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st);
+                            hipStream_t st, bool with_bf16x3) {
+  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3);
   else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st);
   else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
 }

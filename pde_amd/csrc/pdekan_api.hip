@@ -125,7 +125,10 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
       return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
     const int nch = weight_chunks(D, D2, L, n);
-    if (mf) {
+    if (mf && pdekan::bf16x3_weight_eligible(D, D2, L, n)) {
+      ProfScope ps(st, "L%d.bwd_weight.mfma_bf16x3", li);
+      pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st, true);
+    } else if (mf) {
       ProfScope ps(st, "L%d.bwd_weight.mfma", li);
       pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st);
     } else if (pdekan::mfma_skinny_weight_eligible(D, D2, L)) {

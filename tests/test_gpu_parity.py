@@ -326,6 +326,72 @@ def test_moved_grid_takes_the_general_basis_path():
             off += n
 
 
+def _points_clear_of_knots(m_cpu, n, act, seed, clearance=1e-6):
+    """Seeded points none of whose hidden activations sits within `clearance` of a knot of the next layer.
+    The third derivative of a cubic B-spline jumps at the knots and enters the input gradients, so a value
+    within fp32 rounding of a knot (it happens once in ~10^5 activations) makes the gradients of the layers
+    below depend on which side the rounding falls: any fp32 implementation, the reference's included, can
+    differ from the fp64 oracle there by the whole contribution of that point."""
+    layers = O.layers_from_state_dict(m_cpu.state_dict(), dtype=torch.float64)
+    x = torch.rand(n + n // 8 + 16, m_cpu.layers[0].in_features, generator=torch.Generator().manual_seed(seed))
+    h, clear = x.double(), torch.ones(x.size(0), dtype=torch.bool)
+    for li in range(len(layers) - 1):
+        h = O.layer_forward(h, layers[li], act)
+        clear &= (h[:, :, None] - layers[li + 1]["grid"][None, :, :]).abs().amin(dim=(1, 2)) >= clearance
+    x = x[clear]
+    assert x.size(0) >= n
+    return x[:n].contiguous()
+
+
+def _grads_vs_oracle(m_cpu, x, act, widths, tol=TOL):
+    from pde_amd.pinn import BlackScholesStep
+    ref = O.pinn_step(x.double(), O.layers_from_state_dict(m_cpu.state_dict(), dtype=torch.float64), act)
+    ref32 = O.pinn_step(x, O.layers_from_state_dict({k: v.clone() for k, v in m_cpu.state_dict().items()}), act)
+    m = m_cpu.cuda()
+    step = BlackScholesStep(m)
+    loss = step(x.cuda()).item()
+    assert abs(loss - ref["loss"].item()) <= tol * abs(ref["loss"].item())
+    off = 0
+    for l in range(len(widths) - 1):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            r64 = ref["grads"][l][k].flatten()
+            n = r64.numel()
+            # the fp32 bar, plus what the reference algorithm itself loses in fp32 on this model
+            bar = tol + max_rel(ref32["grads"][l][k].flatten(), r64)
+            assert max_rel(step.flat_grad[off:off + n].cpu(), r64) <= bar, (l, k)
+            off += n
+    return step
+
+
+@pytest.mark.parametrize("act", ["silu", "identity"])
+@pytest.mark.parametrize("widths,N", [([2, 64, 64, 1], 16), ([2, 64, 64, 1], 4112), ([2, 64, 128, 64, 1], 1040)])
+def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
+    """Grid 10, equally spaced knots, N a multiple of 16: the weight gradients of the wide hidden layers come
+    from the split-bf16 matrix kernel (three bf16 pieces per fp32 operand, six products).  Against the fp64
+    oracle at the fp32 bar, and against the fp32 matrix kernel on the same inputs."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, 10, 41 + N, act=torch.nn.SiLU if act == "silu" else torch.nn.Identity)
+    x = _points_clear_of_knots(m, N, act, 8)
+    step = _grads_vs_oracle(m, x, act, widths)
+    g_split = step.flat_grad.clone()
+    monkeypatch.setenv("PDEKAN_DISABLE_BF16X3", "1")
+    step32 = BlackScholesStep(m.cuda())
+    step32(x.cuda())
+    monkeypatch.delenv("PDEKAN_DISABLE_BF16X3")
+    assert max_rel(g_split.cpu(), step32.flat_grad.cpu()) <= 2e-6
+
+
+def test_split_bf16_and_fp32_blocks_share_one_layer():
+    """A 64-input layer whose features 32..63 have a moved knot: their block of 32 features takes the fp32 matrix
+    kernel with the general basis path, features 0..31 the split-bf16 kernel, in the same launch pair."""
+    m = _random_model([2, 64, 64, 1], 10, 90)
+    with torch.no_grad():
+        m.layers[1].grid[32:, 7] += 2e-3
+        m.layers[1].grid[40, 3] -= 1e-3
+    x = _points_clear_of_knots(m, 2048, "silu", 91)
+    _grads_vs_oracle(m, x, "silu", [2, 64, 64, 1])
+
+
 @pytest.mark.parametrize("widths,G,N", [([600, 2, 1], 5, 7), ([3000, 2, 1], 5, 1), ([300, 3, 1], 64, 5)])
 def test_wide_input_layer_matches_oracle(widths, G, N):
     """Layers wider than one LDS window of the streaming kernels (the branch

@@ -113,6 +113,27 @@ def test_equal_spacing_fast_path_matches_dense_cox_de_boor(hm, G):
     assert worst < 5e-6, worst
 
 
+@pytest.mark.parametrize("G", [5, 10])
+def test_loop_free_equal_spacing_path_is_the_same_function(hm, G):
+    """eval_basis_uniform_straight (selects instead of loops) against eval_basis_uniform: bit-identical,
+    including at the knots, outside the grid and for non-finite input."""
+    knots = O.uniform_grid(1, G)[0].numpy().copy()
+    h = 2.0 / G
+    around = np.concatenate([np.nextafter(knots, -np.inf), knots, np.nextafter(knots, np.inf)])
+    xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 2001), around,
+                         [-7.0, 9.0, 1e30, -1e30, np.inf, -np.inf]]).astype(np.float32)
+    a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    ca, ia, cb, ib = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for x in xs:
+        hm.hm_eval_basis_row(fptr(knots), len(knots), 1, ctypes.c_float(x), fptr(a), ctypes.byref(ca), ctypes.byref(ia))
+        hm.hm_eval_basis_uniform_straight(fptr(knots), len(knots), ctypes.c_float(x), fptr(b), ctypes.byref(cb),
+                                          ctypes.byref(ib))
+        assert ia.value == ib.value
+        if ia.value:
+            assert ca.value == cb.value, x
+        assert np.array_equal(a, b), x
+
+
 def test_local_basis_nonuniform_knots(hm):
     rng = np.random.default_rng(0)
     knots = np.sort(rng.uniform(-2, 2, 12)).astype(np.float32)
