@@ -516,7 +516,7 @@ constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 
 //   region 1        fetch xraw of step s+2
 //   regions 1..3    cut the pairs' 5 columns into planes
 //   regions 3..6    cut gY tile 0..3 of step s+1 into planes (Gn); regions 4..6 fetch tiles 0..2 of step s+2
-//   region 5        park the pairs' planes (every operand read of the E tile of step s has been issued by then)
+//   region 4        read the operands of tiles 5 and 6, then park the pairs' planes of step s+1
 //   region 6        read the first operands of step s+1
 template <int C1, int ACT>
 __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const GyPlanes& G, GyPlanes& Gn, TileOps& cur,
@@ -530,10 +530,13 @@ __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const 
   const unsigned* esrc = sE + r * RW + q * 4;
   PairJets pj;
   PairPlanes pp;
+  TileOps last;                              // operands of tile 6, read one region early so that the park can go early
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     TileOps nxt;
-    if (t + 1 < NT) nxt = read_tile<COLS, RW>(esrc, t + 1);
+    if (t + 1 < NT - 1) nxt = read_tile<COLS, RW>(esrc, t + 1);
+    if (t == NT - 3) last = read_tile<COLS, RW>(esrc, NT - 1);
+    if (t == NT - 2) nxt = last;
     if (t == 0) {
       expand_pair<ACT>(knots, nk, xraw, pj);
 #pragma unroll
@@ -548,11 +551,11 @@ __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const 
 #pragma unroll
       for (int e = 0; e < 2; ++e) graw[t - 4][e] = ld16(grow2, goff + (unsigned)(e * O + (t - 4) * 16) * 16u);
     }
-    if (t == 5) {
+    if (t == NT - 3) {                       // every operand read of this step's E tile has been issued
       unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
       park_pair<C1, COLS, RW>(base, sE + (f_local * C1) * RW + 16, pp, pj.c0, prev_c0);
     }
-    if (t == 6) nxt = read_tile<COLS, RW>(esrc, 0);
+    if (t == NT - 1) nxt = read_tile<COLS, RW>(esrc, 0);
     mfma_tile(acc[t], cur, G);
     cur = nxt;
     __builtin_amdgcn_sched_barrier(0);
