@@ -414,16 +414,6 @@ __device__ __forceinline__ Planes2 split_jet(float4 v) {
   return r;
 }
 
-__device__ __forceinline__ void split_gy(const float4 (&g)[4][2], GyPlanes& G) {
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const Planes2 p0 = split_jet(g[m][0]), p1 = split_jet(g[m][1]);
-    G.h[m] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
-    G.m[m] = (u32x4){p0.m.x, p0.m.y, p1.m.x, p1.m.y};
-    G.l[m] = (u32x4){p0.l.x, p0.l.y, p1.l.x, p1.l.y};
-  }
-}
-
 __device__ __forceinline__ void split_gy_tile(const float4 (&g)[2], GyPlanes& G, int m) {
   const Planes2 p0 = split_jet(g[0]), p1 = split_jet(g[1]);
   G.h[m] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
