@@ -1,5 +1,7 @@
-// Dense fp32-MFMA path for wide hidden KAN layers on gfx950, J = 4 jets per
-// scalar (value, d/dS, d/dt, d2/dS2).
+// Dense matrix-core path for wide hidden KAN layers on gfx950, J = 4 jets per
+// scalar (value, d/dS, d/dt, d2/dS2): fp32 MFMA kernels for all three
+// contractions, and a split-bf16 MFMA kernel (fp32 accuracy, see its own
+// header below) for the weight gradients of layers with equally spaced knots.
 //
 // With the 4 jets of a point stacked as 4 matrix rows, one layer is three
 // GEMM-shaped contractions over K = in_features * C1 expanded basis columns
