@@ -188,6 +188,24 @@ KAN_HD void eval_basis_uniform_straight(const KnotPtr g, int nk, float inv_h, fl
   uniform_cubic_pieces<kNeedD3>(t, out.inside, inv_h, out);
 }
 
+// For kernels that need B, B' and B'' only (weight gradients): the interval comes from the quotient alone,
+// with g[0], g[nk-1] and 1/h passed in (registers), so the only knot read is g[s] and nothing depends on a
+// comparison against a neighbouring knot.  When rounding puts x a hair outside [g_s, g_{s+1}) the piece of the
+// neighbouring interval is evaluated a rounding error outside [0,1): B, B' and B'' are continuous across knots, so
+// the values agree with the exact interval's to that rounding error.  The third derivative is NOT continuous
+// there: out.d3 is left zero.
+template <typename KnotPtr>
+KAN_HD void eval_basis_uniform_by_quotient(const KnotPtr g, int nk, float g0, float glast, float inv_h, float x,
+                                           Basis& out) {
+  const float u = (x - g0) * inv_h;
+  const int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
+  const float gs = g[s];
+  out.c0 = s - kOrder;
+  out.inside = (int)(x >= g0) & (int)(x < glast);
+  const float t = out.inside ? (x - gs) * inv_h : 0.0f;
+  uniform_cubic_pieces<false>(t, out.inside, inv_h, out);
+}
+
 // 1/h when the nk knots are equally spaced to within 1e-6*h, else 0.  The default
 // grids of grid_size 5 and 10 are (fp32 rounding of the knot values moves their
 // spacing by <= 4.5e-7*h); at grid_size 20 the rounding is 1.5e-6*h, which would

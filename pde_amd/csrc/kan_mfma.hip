@@ -427,10 +427,12 @@ __device__ __forceinline__ void split_gy_tile(const float4 (&g)[2], GyPlanes& G,
 struct PairJets { float4 col[5]; int c0; };
 struct PairPlanes { Planes2 col[5]; };
 
+struct FeatureGrid { float g0, glast, inv_h; };            // of this lane's feature: constant over the kernel
+
 template <int ACT>
-__device__ __forceinline__ void expand_pair(const float* knots, int nk, float4 jet, PairJets& out) {
+__device__ __forceinline__ void expand_pair(const float* knots, int nk, const FeatureGrid& fg, float4 jet, PairJets& out) {
   Basis bs;
-  eval_basis_uniform_straight<false>(knots, nk, knots[nk], jet.x, bs);
+  eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet.x, bs);
   const Act av = eval_act(ACT, jet.x);
   const float s2 = jet.y * jet.y;
 #pragma unroll
@@ -513,7 +515,7 @@ constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 
 template <int C1, int ACT>
 __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const GyPlanes& G, GyPlanes& Gn, TileOps& cur,
                                             float4 (&graw)[4][2], float4& xraw, unsigned* sE, const float* knots,
-                                            int& prev_c0, const char* __restrict__ xrow2, const char* __restrict__ grow1,
+                                            const FeatureGrid& fg, int& prev_c0, const char* __restrict__ xrow2, const char* __restrict__ grow1,
                                             const char* __restrict__ grow2, unsigned xoff, unsigned goff, int lane,
                                             int O) {
   constexpr int COLS = 8 * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
@@ -530,7 +532,7 @@ __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const 
     if (t == NT - 3) last = read_tile<COLS, RW>(esrc, NT - 1);
     if (t == NT - 2) nxt = last;
     if (t == 0) {
-      expand_pair<ACT>(knots, nk, xraw, pj);
+      expand_pair<ACT>(knots, nk, fg, xraw, pj);
 #pragma unroll
       for (int e = 0; e < 2; ++e) graw[3][e] = ld16(grow1, goff + (unsigned)(e * O + 3 * 16) * 16u);
     }
@@ -586,6 +588,8 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
   }
   for (int idx = lane; idx < 3 * COLS * RW; idx += 64) sE[idx] = 0u;
   const float* knots = sK + f_local * kKnotPad;
+  const FeatureGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
+                          ginfo[i0 + f_local]};
 
   f32x4 acc[NT][4];
 #pragma unroll
@@ -620,7 +624,7 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
       xraw = ld16(xb + (pbeg + 8) * xstride, xoff);
       PairJets pj;
       PairPlanes pp;
-      expand_pair<ACT>(knots, nk, x0, pj);
+      expand_pair<ACT>(knots, nk, fg, x0, pj);
 #pragma unroll
       for (int m = 0; m < 5; ++m) pp.col[m] = split_jet(pj.col[m]);
       unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
@@ -632,9 +636,9 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
     for (int64_t pb = pbeg; pb < pend; pb += 16) {
       // past the end of the chunk: any valid rows, fetched (and expanded) but never used
       const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
-      bf16x3_step<C1, ACT>(acc, GA, GB, cur, graw, xraw, sE, knots, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
+      bf16x3_step<C1, ACT>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
                            gb + p2 * gstride, xoff, goff, lane, O);
-      bf16x3_step<C1, ACT>(acc, GB, GA, cur, graw, xraw, sE, knots, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
+      bf16x3_step<C1, ACT>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
                            gb + p3 * gstride, xoff, goff, lane, O);
     }
   }

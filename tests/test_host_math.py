@@ -134,6 +134,37 @@ def test_loop_free_equal_spacing_path_is_the_same_function(hm, G):
         assert np.array_equal(a, b), x
 
 
+@pytest.mark.parametrize("G", [5, 10])
+def test_quotient_interval_path_matches_up_to_the_second_derivative(hm, G):
+    """eval_basis_uniform_by_quotient picks the interval without comparing against the knots; at a knot tie it may
+    sit one interval off and evaluate the neighbouring piece a rounding error outside [0,1).  B, B', B'' (dense
+    over the columns) must still agree with the exact-interval path everywhere, ties included: to fp32 rounding
+    away from the knots, and at a tie to the mismatch between the stored knot spacing and 1/h (the grid counts as
+    equally spaced up to 1e-6 h), which moves t by that much across the joint."""
+    knots = O.uniform_grid(1, G)[0].numpy().copy()
+    C = G + 3
+    h = 2.0 / G
+    around = np.concatenate([np.nextafter(knots, -np.inf), knots, np.nextafter(knots, np.inf)])
+    xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 2001), around,
+                         [-7.0, 9.0, 1e30, -1e30]]).astype(np.float32)
+    a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    ca, ia, cb, ib = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    scale = np.array([1.0, 1 / h, 1 / h ** 2])[:, None]
+    worst = 0.0
+    for x in xs:
+        hm.hm_eval_basis_row(fptr(knots), len(knots), 1, ctypes.c_float(x), fptr(a), ctypes.byref(ca), ctypes.byref(ia))
+        hm.hm_eval_basis_uniform_by_quotient(fptr(knots), len(knots), ctypes.c_float(x), fptr(b), ctypes.byref(cb),
+                                             ctypes.byref(ib))
+        assert ia.value == ib.value
+        da, db = np.zeros((3, C)), np.zeros((3, C))
+        for m in range(4):
+            for dense, out, c0 in ((da, a, ca.value), (db, b, cb.value)):
+                if 0 <= c0 + m < C:
+                    dense[:, c0 + m] = out[m:12:4]
+        worst = max(worst, np.abs((da - db) / scale).max())
+    assert worst < 4e-6, worst
+
+
 def test_local_basis_nonuniform_knots(hm):
     rng = np.random.default_rng(0)
     knots = np.sort(rng.uniform(-2, 2, 12)).astype(np.float32)
