@@ -1011,9 +1011,12 @@ void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float*
   else fwd_launch<9, 4>(L, a, wt, y, N, st);
 }
 
-// split-bf16 weight gradients: grid 10 (8 features x 14 columns = 7 column tiles), whole pairs of 8-point steps
+// split-bf16 weight gradients: grid 10 (8 features x 14 columns = 7 column tiles).  The kernel walks whole pairs of
+// 8-point steps; when N is not a multiple of 16 the last N % 16 points go to the fp32 kernel as a chunk of their own
+// (so at least two chunks are needed).
 bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N) {
-  if (!mfma_eligible(D, D2, L) || L.G != 10 || N % 16 != 0 || !L.ginfo) return false;
+  if (!mfma_eligible(D, D2, L) || L.G != 10 || N < 16 || !L.ginfo) return false;
+  if (N % 16 != 0 && mfma_weight_chunks(N, L) < 2) return false;
   const char* off = getenv("PDEKAN_DISABLE_BF16X3");    // A/B switch for tests and profiling
   return !(off && off[0] == '1');
 }
@@ -1023,24 +1026,34 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
                        hipStream_t st, bool with_bf16x3 = false) {
   constexpr int COLS = KIW * C1, ROWS = PB * 4, RS = ROWS + 4;
   const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
-  int64_t chunk = (N + nchunks - 1) / nchunks;
-  const int step_pts = with_bf16x3 ? 16 : PB;            // the split-bf16 kernel walks pairs of 8-point steps
-  chunk = (chunk + step_pts - 1) / step_pts * step_pts;
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
   allow_big_lds(k, lds);
   const int nx = L.I / (4 * KIW), ny = L.O / 64;
-  k<<<(unsigned)(nx * ny * nchunks), 256, lds, st>>>(reinterpret_cast<const float4*>(a),
-                                                     reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part, N, L.I,
-                                                     L.O, L.act, chunk, nx, ny, nchunks, with_bf16x3 ? 1 : 0);
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* g4 = reinterpret_cast<const float4*>(gy);
+  if (!with_bf16x3) {
+    int64_t chunk = (N + nchunks - 1) / nchunks;
+    chunk = (chunk + PB - 1) / PB * PB;
+    k<<<(unsigned)(nx * ny * nchunks), 256, lds, st>>>(a4, g4, L.grid, L.ginfo, part, N, L.I, L.O, L.act, chunk, nx, ny,
+                                                       nchunks, 0);
+    return;
+  }
   if constexpr (C1 % 2 == 0 && KIW == 8 && PB == 8) {
-    if (with_bf16x3) {                                   // the blocks the launch above skipped
-      auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, kActSiLU> : bwd_weight_bf16x3_kernel<C1, kActIdentity>;
-      const size_t lds_b = (size_t)4 * (3 * 8 * C1 * kBf16Rw + 8 * kKnotPad) * 4;
-      allow_big_lds(kb, lds_b);
-      kb<<<(unsigned)(nx * ny * nchunks), 256, lds_b, st>>>(reinterpret_cast<const float4*>(a),
-                                                            reinterpret_cast<const float4*>(gy), L.grid, L.ginfo, part,
-                                                            N, L.I, L.O, chunk, nx, ny, nchunks);
-    }
+    // points [0, N16) in nmain chunks: every block of 32 features goes to exactly one of the two kernels
+    const int64_t N16 = N / 16 * 16, tail = N - N16;
+    const int nmain = tail ? nchunks - 1 : nchunks;
+    int64_t chunk = (N16 + nmain - 1) / nmain;
+    chunk = (chunk + 15) / 16 * 16;
+    k<<<(unsigned)(nx * ny * nmain), 256, lds, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, L.act, chunk, nx, ny,
+                                                     nmain, 1);
+    auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, kActSiLU> : bwd_weight_bf16x3_kernel<C1, kActIdentity>;
+    const size_t lds_b = (size_t)4 * (3 * 8 * C1 * kBf16Rw + 8 * kKnotPad) * 4;
+    allow_big_lds(kb, lds_b);
+    kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain);
+    if (tail)                                            // the last chunk slot: the points past N16, fp32 kernel, all blocks
+      k<<<(unsigned)(nx * ny), 256, lds, st>>>(a4 + (size_t)N16 * L.I, g4 + (size_t)N16 * L.O, L.grid, L.ginfo,
+                                               part + (size_t)nmain * L.packed_floats(), tail, L.I, L.O, L.act, 16, nx, ny,
+                                               1, 0);
   }
 }
 

@@ -364,11 +364,13 @@ def _grads_vs_oracle(m_cpu, x, act, widths, tol=TOL):
 
 
 @pytest.mark.parametrize("act", ["silu", "identity"])
-@pytest.mark.parametrize("widths,N", [([2, 64, 64, 1], 16), ([2, 64, 64, 1], 4112), ([2, 64, 128, 64, 1], 1040)])
+@pytest.mark.parametrize("widths,N", [([2, 64, 64, 1], 16), ([2, 64, 64, 1], 4112), ([2, 64, 128, 64, 1], 1040),
+                                      ([2, 64, 64, 1], 4099)])
 def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
-    """Grid 10, equally spaced knots, N a multiple of 16: the weight gradients of the wide hidden layers come
-    from the split-bf16 matrix kernel (three bf16 pieces per fp32 operand, six products).  Against the fp64
-    oracle at the fp32 bar, and against the fp32 matrix kernel on the same inputs."""
+    """Grid 10, equally spaced knots: the weight gradients of the wide hidden layers come from the split-bf16
+    matrix kernel (three bf16 pieces per fp32 operand, six products); when N is not a multiple of 16 the last
+    N % 16 points take the fp32 kernel as a chunk of their own.  Against the fp64 oracle at the fp32 bar, and
+    against the fp32 matrix kernel on the same inputs."""
     from pde_amd.pinn import BlackScholesStep
     m = _random_model(widths, 10, 41 + N, act=torch.nn.SiLU if act == "silu" else torch.nn.Identity)
     x = _points_clear_of_knots(m, N, act, 8)
