@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
+    ap.add_argument("--base-activation", default="silu", choices=["silu", "identity"],
+                    help="silu = the module default (kan.py:18); identity = what the scripts pass (run1.py:478-482)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip the AdamW update")
     ap.add_argument("--force-dist", action="store_true",
@@ -159,7 +161,8 @@ def main():
     J = 2 * d
 
     torch.manual_seed(0)                                   # reference-compatible seeded init
-    model = KAN(widths, grid_size=grid).to(dev)
+    act_cls = torch.nn.SiLU if args.base_activation == "silu" else torch.nn.Identity
+    model = KAN(widths, grid_size=grid, base_activation=act_cls).to(dev)
     # the same global point set whatever the rank count: rank r takes the r-th contiguous shard
     gen = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(n_local, d, generator=gen).to(dev)
@@ -257,7 +260,7 @@ def main():
         "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name}: KAN {widths} grid={grid} k=3 SiLU, Black-Scholes PINN step "
+        "config": {"workload": f"{name}: KAN {widths} grid={grid} k=3 {'SiLU' if args.base_activation == 'silu' else 'Identity'}, Black-Scholes PINN step "
                                f"(fwd + residual + loss + bwd + AdamW), {n_local} points/GPU, {n_global} total",
                    "points_per_gpu": n_local, "points_total": n_global, "micro_batch": args.micro_batch,
                    "optimizer_in_step": not args.no_optimizer, "parallelism": f"dp{world}"},
@@ -272,8 +275,7 @@ def main():
                     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        act = "silu"
-        out["cpu_baseline"] = cpu_baseline(name, sd0, widths, act)
+        out["cpu_baseline"] = cpu_baseline(name, sd0, widths, args.base_activation)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
