@@ -146,7 +146,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries the one JSON line
+        # the caller parses, so the C-level stdout points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from pde_amd import KAN, _lib
     from pde_amd.dist import DataParallelStep
