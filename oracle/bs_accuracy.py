@@ -1,8 +1,8 @@
 """Accuracy references for a trained Black-Scholes PINN: the closed-form European
 call (B-S.py:5-17) and the implicit finite-difference grid of FDM.py:18-63.
 
-TEST INFRASTRUCTURE ONLY (imported by tests/ and examples/, never by the
-product).  Both are restated in numpy; the finite-difference solver follows
+TEST INFRASTRUCTURE ONLY (imported by tests/, never by the product or the
+examples).  Both are restated in numpy; the finite-difference solver follows
 the reference scheme exactly - fully implicit in time, central in S, S_max =
 3K, the boundary columns held at 0 and S_max - K and NOT folded into the
 right-hand side (FDM.py:24-28, :55-62) - but solves the tridiagonal system

@@ -118,7 +118,16 @@ def test_trained_pinn_prices_the_call():
     spec = importlib.util.spec_from_file_location("bs_pinn_accuracy", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    import numpy as np
+    from oracle.bs_accuracy import closed_form_call, fdm_call_grid
     out = mod.main(["--steps", "800", "--seed", "0"])
     assert out["history"][-1][1] < out["history"][1][1]        # PDE loss falls once the boundary data bite
     assert out["rmse_closed_form"] < 2e-2                      # prices range up to 1.27
-    assert out["rmse_fdm"] < 2e-2
+    K, r, v = out["strike"], out["rate"], out["sigma"]
+    exact = closed_form_call(out["S"], K, out["tau"], r, v)
+    assert np.sqrt(np.mean((out["pred"] - exact) ** 2)) < 2e-2
+    M = 400
+    f = fdm_call_grid(1.0, r, v, M, K, fold_boundary=True)
+    ti = np.rint((1.0 - out["tau"]) * M).astype(int)           # row i = time level; time to expiry = 1 - i/M
+    si = np.rint(out["S"] / (3.0 * K) * M).astype(int)
+    assert np.sqrt(np.mean((out["pred"] - f[ti, si]) ** 2)) < 2e-2
