@@ -241,6 +241,7 @@ def main():
                 "algorithmic_flops_per_launch": live * kd["flops"]}
         if live < 1.0:
             roof["note"] = "fp32 vector ALUs (packed FMA), flops of the live columns only"
+            roof["dense_equivalent_tflops"] = kd["flops"] / (kd["avg_ms"] * 1e-3) / 1e12
     elif dom.endswith(".mfma_bf16x3"):
         # fp32-accurate products made of 6 bf16 products each: price the algorithmic fp32 flops against bf16 peak / 6
         peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
