@@ -555,3 +555,38 @@ def test_fused_step_replays_from_a_hip_graph():
         step(x)
         assert step.loss.item() == loss_g
         assert torch.equal(step.flat_grad, grad_g)
+
+
+@pytest.mark.parametrize("I,O,N", [(32, 64, 48), (96, 64, 1000), (128, 128, 4112), (256, 256, 1000), (64, 256, 2064),
+                                   (32, 128, 16)])
+def test_split_bf16_weight_gradients_over_layer_shapes(I, O, N, monkeypatch):
+    """One grid-10 layer at a time through the layer-level entry points (jet forward + backward with a random
+    cotangent): every block / chunk decode of the split-bf16 weight-gradient kernel (1 to 8 feature blocks, 1 to 4
+    output tiles, ragged N with the fp32 tail chunk) against the fp32 matrix kernel on the same inputs."""
+    from pde_amd.kan import KANLinear
+    torch.manual_seed(I + O)
+    lay = KANLinear(I, O, grid_size=10).cuda()
+    g = torch.Generator().manual_seed(N)
+    xj = torch.randn(N, I, 4, generator=g)
+    xj[:, :, 0] = torch.rand(N, I, generator=g) * 3.6 - 1.8          # also outside the grid [-1.6, 1.6]
+    gy = torch.randn(N, O, 4, generator=g).cuda()
+    xj = xj.cuda()
+    grads = []
+    for off in (None, "1"):
+        if off:
+            monkeypatch.setenv("PDEKAN_DISABLE_BF16X3", off)
+        for p in lay.parameters():
+            p.grad = None
+        lay.forward_jet(xj, 2, 1).backward(gy)
+        grads.append([p.grad.clone() for p in lay.parameters()])
+    monkeypatch.delenv("PDEKAN_DISABLE_BF16X3")
+    # heavy-tailed random jets: each kernel's fp32 accumulation alone sits 1e-6 to 3e-6 from an fp64 sum here
+    for a, b in zip(*grads):
+        assert max_rel(a.cpu(), b.cpu()) <= 5e-6
+    x = xj.double().cpu()
+    x0, sg = x[..., 0], torch.sigmoid(x[..., 0])
+    f0, f1, f2 = x0 * sg, sg * (1 + x0 * (1 - sg)), sg * (1 - sg) * (2 + x0 * (1 - 2 * sg))
+    aj = torch.stack([f0, f1 * x[..., 1], f1 * x[..., 2], f2 * x[..., 1] ** 2 + f1 * x[..., 3]], -1)
+    exact = torch.einsum("noj,nij->oi", gy.double().cpu(), aj)
+    for gset in grads:
+        assert max_rel(gset[0].double().cpu(), exact) <= 5e-6
