@@ -36,11 +36,11 @@ __device__ __forceinline__ void load_knots_to_lds(float* s_knots, const float* g
   }
 }
 
-// per feature: 1/h when its knots are equally spaced (see equal_spacing_inv_h), else 0
+// per feature: 1/h when its knots are equally spaced, -1/h when nearly so, else 0 (see knot_spacing_info)
 // (e.g. a grid moved by update_grid, kan.py:168-215)
 __global__ void grid_info_kernel(const float* __restrict__ grid, float* __restrict__ ginfo, int I, int nk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < I) ginfo[i] = equal_spacing_inv_h(grid + (size_t)i * nk, nk);
+  if (i < I) ginfo[i] = knot_spacing_info(grid + (size_t)i * nk, nk);
 }
 
 // --------------------------------------------------------------------------

@@ -13,7 +13,7 @@ struct LayerView {
   const float* base_w;     // [O][I]
   const float* spline_w;   // [O][I][G+3]
   const float* scaler;     // [O][I] or nullptr
-  const float* ginfo;      // [I]: 1/h of a feature whose knots are equally spaced, else 0; nullptr = unknown
+  const float* ginfo;      // [I]: per feature 1/h (knots equally spaced), -1/h (nearly) or 0, see knot_spacing_info; nullptr = unknown
   int C() const { return G + 3; }
   int C1() const { return G + 4; }
   int nk() const { return G + 7; }

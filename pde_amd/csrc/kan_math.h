@@ -206,6 +206,53 @@ KAN_HD void eval_basis_uniform_by_quotient(const KnotPtr g, int nk, float g0, fl
   uniform_cubic_pieces<false>(t, out.inside, inv_h, out);
 }
 
+// B, B' and B'' on ANY knot row whose quotient guess floor((x - g_0)/h) is at most one interval off (see
+// knot_spacing_info), again without a loop, a branch or a dependent chain of knot reads: the 8 knots around the
+// guess are read at once, the interval is settled by two comparisons in registers and the general triangle of
+// eval_basis runs on the 6 knots selected.  gp points at knot 0 of a row stored with its first knot repeated 3
+// times in front and its last knot 4 times behind (the reads g[s-3] .. g[s+4] need no index clamp; a repeated
+// knot only ever feeds a basis whose index is outside [0, C-1], which callers drop, and every denominator below
+// spans [g_s, g_{s+1}], so none is zero).  out.d3 is left zero.
+template <typename KnotPtr>
+KAN_HD void eval_basis_near_uniform(const KnotPtr gp, int nk, float g0, float glast, float inv_h, float x, Basis& out) {
+  const float u = (x - g0) * inv_h;
+  int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
+  const float a0 = gp[s - 3], a1 = gp[s - 2], a2 = gp[s - 1], a3 = gp[s], a4 = gp[s + 1], a5 = gp[s + 2],
+              a6 = gp[s + 3], a7 = gp[s + 4];
+  const bool down = (s > 0) & (x < a3), up = (s < nk - 2) & (x >= a4);
+  const float km2 = down ? a0 : (up ? a2 : a1);
+  const float km1 = down ? a1 : (up ? a3 : a2);
+  const float k0 = down ? a2 : (up ? a4 : a3);
+  const float k1 = down ? a3 : (up ? a5 : a4);
+  const float k2 = down ? a4 : (up ? a6 : a5);
+  const float k3 = down ? a5 : (up ? a7 : a6);
+  s += (int)up - (int)down;
+  out.c0 = s - kOrder;
+  out.inside = (int)(x >= g0) & (int)(x < glast);
+  const float r1 = kan_rcp(k1 - k0);
+  const float r2a = kan_rcp(k1 - km1), r2b = kan_rcp(k2 - k0);
+  const float r3a = kan_rcp(k1 - km2), r3b = kan_rcp(k2 - km1), r3c = kan_rcp(k3 - k0);
+  const float b1a = (k1 - x) * r1, b1b = (x - k0) * r1;
+  const float u_a = b1a * r2a, u_b = b1b * r2b;
+  const float b2a = (k1 - x) * u_a, b2b = (x - km1) * u_a + (k2 - x) * u_b, b2c = (x - k0) * u_b;
+  const float q_a = b2a * r3a, q_b = b2b * r3b, q_c = b2c * r3c;
+  const float w_a = -2.0f * u_a * r3a, w_b = 2.0f * (u_a - u_b) * r3b, w_c = 2.0f * u_b * r3c;
+  const bool in = out.inside != 0;            // selects, not products: NaN / inf must not leak from outside the grid
+  out.b[0] = in ? (k1 - x) * q_a : 0.0f;
+  out.b[1] = in ? (x - km2) * q_a + (k2 - x) * q_b : 0.0f;
+  out.b[2] = in ? (x - km1) * q_b + (k3 - x) * q_c : 0.0f;
+  out.b[3] = in ? (x - k0) * q_c : 0.0f;
+  out.d1[0] = in ? -3.0f * q_a : 0.0f;
+  out.d1[1] = in ? 3.0f * (q_a - q_b) : 0.0f;
+  out.d1[2] = in ? 3.0f * (q_b - q_c) : 0.0f;
+  out.d1[3] = in ? 3.0f * q_c : 0.0f;
+  out.d2[0] = in ? -3.0f * w_a : 0.0f;
+  out.d2[1] = in ? 3.0f * (w_a - w_b) : 0.0f;
+  out.d2[2] = in ? 3.0f * (w_b - w_c) : 0.0f;
+  out.d2[3] = in ? 3.0f * w_c : 0.0f;
+  out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
+}
+
 // 1/h when the nk knots are equally spaced to within 1e-6*h, else 0.  The default
 // grids of grid_size 5 and 10 are (fp32 rounding of the knot values moves their
 // spacing by <= 4.5e-7*h); at grid_size 20 the rounding is 1.5e-6*h, which would
@@ -218,8 +265,28 @@ KAN_HD float equal_spacing_inv_h(const KnotPtr g, int nk) {
   return (h > 0.0f && dev <= 1e-6f * h) ? 1.0f / h : 0.0f;
 }
 
+// What the kernels know about a feature's knot row, in one float:
+//    1/h   equally spaced (see above): the fixed polynomial pieces apply;
+//   -1/h   not equally spaced, but increasing with every knot within h/4 of g_0 + k*h, h = (g_last - g_0)/(nk-1):
+//          floor((x - g_0)/h) is then at most one interval away from the interval that holds x
+//          (eval_basis_near_uniform); the default grid of grid_size 20 is of this kind;
+//    0     anything else (a grid moved by update_grid): interval search.
+template <typename KnotPtr>
+KAN_HD float knot_spacing_info(const KnotPtr g, int nk) {
+  const float eq = equal_spacing_inv_h(g, nk);
+  if (eq > 0.0f) return eq;
+  const float g0 = g[0], h = (g[nk - 1] - g0) / (float)(nk - 1);
+  if (!(h > 0.0f)) return 0.0f;
+  bool ok = true;
+  for (int k = 0; k < nk; ++k) {
+    ok = ok && fabsf(g[k] - (g0 + (float)k * h)) <= 0.25f * h;
+    if (k + 1 < nk) ok = ok && (g[k + 1] > g[k]);
+  }
+  return ok ? -1.0f / h : 0.0f;
+}
+
 // Knot rows staged in LDS carry one extra float after the nk knots: 1/h when the
-// feature's knots are equally spaced, 0 otherwise (see grid_info_kernel).
+// feature's knots are equally spaced, 0 or negative otherwise (knot_spacing_info).
 template <bool kNeedD3, typename KnotPtr>
 KAN_HD void eval_basis_row(const KnotPtr row, int nk, float x, Basis& out) {
   const float inv_h = row[nk];

@@ -31,6 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kKnotPad = 28;   // >= G+7 knots + 1 slot for the feature's 1/h, G <= 20
+constexpr int kKnotPadGen = 36;   // >= G+7 knots + 3 + 4 repeated end knots (bwd_weight_bf16x3_kernel, GEN)
 
 // k-th float of the staged knot row of a feature: a knot, or (k == nk) its 1/h / 0
 __device__ __forceinline__ float knot_row_value(const float* grid, const float* ginfo, int feature, int k, int nk) {
@@ -255,7 +256,7 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
     }
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // blocks whose features all have equally spaced knots belong to bwd_weight_bf16x3_kernel when it runs too
+  // blocks whose features all have (nearly) equally spaced knots belong to bwd_weight_bf16x3_kernel when it runs too
   if (skip_uniform && __builtin_amdgcn_ballot_w64(ginfo[bx * 4 * KIW + lane % (4 * KIW)] != 0.0f) == ~0ull) return;
   const int p_local = lane % PB, f_local = lane / PB;
   const bool gen_lane = f_local < KIW;
@@ -367,9 +368,10 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 // order of an fp32 product's own rounding, and the matrix work costs 6/16 of
 // the fp32-MFMA time.
 //
-// Every wave is on its own (no block barrier): wave = 8 features x C1 columns
-// (NT = 8*C1/16 column tiles) x 64 outputs of accumulators over a chunk of
-// points, walked 8 points (K = 8 x 4 jets = 32 = one MFMA) at a time.  One wave
+// Every wave is on its own (no block barrier): wave = FE features x C1 columns
+// (NT = FE*C1/16 column tiles: 8 x 14 for grid 10, 4 x 24 for grid 20) x 64
+// outputs of accumulators over a chunk of points, walked 8 points (K = 8 x 4
+// jets = 32 = one MFMA) at a time.  One wave
 // per SIMD, so the instruction stream itself is software-pipelined: the vector
 // work that prepares step s+1 sits between the matrix instructions of step s.
 //   B operand (gY): lane (r = lane&15, q = lane>>4) holds output 16m + r, jets of
@@ -383,9 +385,13 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 //     read back in MFMA operand order (ds_read_b128).  LDS operations of a
 //     wave complete in order, so the tile of step s+1 is written right after
 //     the last operand read of step s has been issued.
-// A block (4 waves = 32 features) returns at once unless all its 32 features have
-// equally spaced knots; bwd_weight_mfma_kernel, launched with skip_uniform = 1
-// on the same grid, then does exactly the blocks this kernel leaves out.
+// Two variants share everything but the basis evaluation: GEN = false for knot
+// rows that are equally spaced, GEN = true for rows that are only nearly so
+// (knot_spacing_info: the default grid of grid_size 20).  Both are launched on
+// the same grid; a block (4 waves = 4*FE features) returns at once unless its
+// features are all of the variant's kind (one row that is only nearly equally
+// spaced sends the block to GEN = true).  bwd_weight_mfma_kernel, launched with
+// skip_uniform = 1 on the same grid, does exactly the blocks both leave out.
 // Output: part[chunk][O][I][C1].
 // ==========================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -429,10 +435,13 @@ struct PairPlanes { Planes2 col[5]; };
 
 struct FeatureGrid { float g0, glast, inv_h; };            // of this lane's feature: constant over the kernel
 
-template <int ACT>
+// GEN = false: knots equally spaced (fixed polynomial pieces); GEN = true: nearly so (general triangle on the
+// knots around the quotient guess; the row is stored with repeated end knots, see eval_basis_near_uniform)
+template <int ACT, bool GEN>
 __device__ __forceinline__ void expand_pair(const float* knots, int nk, const FeatureGrid& fg, float4 jet, PairJets& out) {
   Basis bs;
-  eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet.x, bs);
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, jet.x, bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet.x, bs);
   const Act av = eval_act(ACT, jet.x);
   const float s2 = jet.y * jet.y;
 #pragma unroll
@@ -502,7 +511,8 @@ __device__ __forceinline__ float4 ld16(const char* __restrict__ row, unsigned of
 
 constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 16 bytes of pad (bank spread; dump slot)
 
-// One step = 8 points = NT = 7 regions of 24 matrix instructions (one column tile each), fenced so that each
+// One step = 8 points = NT regions of 24 matrix instructions (one column tile each; NT = 7 is described, NT = 6
+// moves everything from region 3 on one region earlier), fenced so that each
 // region keeps its own share of the vector work that prepares step s+1 (one wave per SIMD: nothing else would
 // fill the matrix instructions' issue gaps).  graw / xraw hold the raw rows of step s+1 on entry; each piece is
 // fetched again (rows of step s+2, at pnext2) right after the region that consumed it:
@@ -512,15 +522,15 @@ constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 
 //   regions 3..6    cut gY tile 0..3 of step s+1 into planes (Gn); regions 4..6 fetch tiles 0..2 of step s+2
 //   region 4        read the operands of tiles 5 and 6, then park the pairs' planes of step s+1
 //   region 6        read the first operands of step s+1
-template <int C1, int ACT>
-__device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const GyPlanes& G, GyPlanes& Gn, TileOps& cur,
+template <int C1, int FE, int ACT, bool GEN>
+__device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[FE * C1 / 16][4], const GyPlanes& G, GyPlanes& Gn, TileOps& cur,
                                             float4 (&graw)[4][2], float4& xraw, unsigned* sE, const float* knots,
                                             const FeatureGrid& fg, int& prev_c0, const char* __restrict__ xrow2, const char* __restrict__ grow1,
                                             const char* __restrict__ grow2, unsigned xoff, unsigned goff, int lane,
                                             int O) {
-  constexpr int COLS = 8 * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
-  static_assert(NT == 7, "the region plan below is written for 7 column tiles");
-  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = lane >> 3;
+  constexpr int COLS = FE * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
+  static_assert(NT == 6 || NT == 7, "the region plan below is written for 6 or 7 column tiles");
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
   const unsigned* esrc = sE + r * RW + q * 4;
   PairJets pj;
   PairPlanes pp;
@@ -532,18 +542,19 @@ __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const 
     if (t == NT - 3) last = read_tile<COLS, RW>(esrc, NT - 1);
     if (t == NT - 2) nxt = last;
     if (t == 0) {
-      expand_pair<ACT>(knots, nk, fg, xraw, pj);
+      expand_pair<ACT, GEN>(knots, nk, fg, xraw, pj);
 #pragma unroll
       for (int e = 0; e < 2; ++e) graw[3][e] = ld16(grow1, goff + (unsigned)(e * O + 3 * 16) * 16u);
     }
     if (t == 1) xraw = ld16(xrow2, xoff);
     if (t == 1) { pp.col[0] = split_jet(pj.col[0]); pp.col[1] = split_jet(pj.col[1]); }
     if (t == 2) { pp.col[2] = split_jet(pj.col[2]); pp.col[3] = split_jet(pj.col[3]); }
-    if (t == 3) pp.col[4] = split_jet(pj.col[4]);
-    if (t >= 3) split_gy_tile(graw[t - 3], Gn, t - 3);
-    if (t >= 4) {
+    if (t == NT - 4) pp.col[4] = split_jet(pj.col[4]);
+    if (t >= NT - 4) split_gy_tile(graw[t - (NT - 4)], Gn, t - (NT - 4));
+    if (t >= NT - 3) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) graw[t - 4][e] = ld16(grow2, goff + (unsigned)(e * O + (t - 4) * 16) * 16u);
+      for (int e = 0; e < 2; ++e)
+        graw[t - (NT - 3)][e] = ld16(grow2, goff + (unsigned)(e * O + (t - (NT - 3)) * 16) * 16u);
     }
     if (t == NT - 3) {                       // every operand read of this step's E tile has been issued
       unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
@@ -556,14 +567,17 @@ __device__ __forceinline__ void bf16x3_step(f32x4 (&acc)[8 * C1 / 16][4], const 
   }
 }
 
-template <int C1, int ACT>
+template <int C1, int FE, int ACT, bool GEN>
 __global__ void __launch_bounds__(256, 1)
 bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict__ gy,
                          const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
                          int64_t N, int I, int O, int64_t chunk_pts, int nx, int ny, int nz) {
-  constexpr int COLS = 8 * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
-  static_assert(COLS % 16 == 0, "16-wide column tiles");
-  constexpr int kWaveWords = 3 * COLS * RW + 8 * kKnotPad;
+  constexpr int COLS = FE * C1, NT = COLS / 16, RW = kBf16Rw, nk = C1 + 3;
+  static_assert(COLS % 16 == 0 && (FE == 8 || FE == 4), "16-wide column tiles; 8 points x FE features per step");
+  static_assert(nk + 1 <= kKnotPad, "knot row + 1/h fit the padded row");
+  constexpr int KP = GEN ? kKnotPadGen : kKnotPad;        // floats per staged knot row
+  static_assert(nk + 7 <= kKnotPadGen, "knot row with 3 + 4 repeated end knots fits");
+  constexpr int kWaveWords = 3 * COLS * RW + FE * KP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bx, by, bz;                            // same decode as bwd_weight_mfma_kernel
   {
@@ -576,20 +590,33 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
     }
   }
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  if (__builtin_amdgcn_ballot_w64(ginfo[bx * 32 + (lane & 31)] != 0.0f) != ~0ull) return;
+  {                                          // the block's features: all equally spaced -> GEN = false takes it;
+    const float gi = ginfo[bx * 4 * FE + lane % (4 * FE)];          // all at least nearly so -> GEN = true
+    const bool all_near = __builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull;
+    const bool all_equal = __builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull;
+    if (!all_near || all_equal == GEN) return;
+  }
 
   unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;   // this wave's tile: [3][COLS][RW]
-  float* sK = reinterpret_cast<float*>(sE + 3 * COLS * RW);               // and its 8 knot rows
-  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = lane >> 3;
-  const int i0 = (bx * 4 + wave) * 8, o0 = by * 64;
-  for (int idx = lane; idx < 8 * (nk + 1); idx += 64) {
-    const int f = idx / (nk + 1), k = idx - f * (nk + 1);
-    sK[f * kKnotPad + k] = knot_row_value(grid, ginfo, i0 + f, k, nk);
+  float* sK = reinterpret_cast<float*>(sE + 3 * COLS * RW);               // and its FE knot rows
+  // FE = 4: lanes 32..63 repeat the pairs of lanes 0..31 (same values to the same LDS words)
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
+  const int i0 = (bx * 4 + wave) * FE, o0 = by * 64;
+  if constexpr (GEN) {                       // [g_0 x3][the nk knots][g_last x4]
+    for (int idx = lane; idx < FE * KP; idx += 64) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = grid[(size_t)(i0 + f) * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = lane; idx < FE * (nk + 1); idx += 64) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = knot_row_value(grid, ginfo, i0 + f, k, nk);
+    }
   }
   for (int idx = lane; idx < 3 * COLS * RW; idx += 64) sE[idx] = 0u;
-  const float* knots = sK + f_local * kKnotPad;
+  const float* knots = sK + f_local * KP + (GEN ? 3 : 0);
   const FeatureGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
-                          ginfo[i0 + f_local]};
+                          fabsf(ginfo[i0 + f_local])};
 
   f32x4 acc[NT][4];
 #pragma unroll
@@ -624,7 +651,7 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
       xraw = ld16(xb + (pbeg + 8) * xstride, xoff);
       PairJets pj;
       PairPlanes pp;
-      expand_pair<ACT>(knots, nk, fg, x0, pj);
+      expand_pair<ACT, GEN>(knots, nk, fg, x0, pj);
 #pragma unroll
       for (int m = 0; m < 5; ++m) pp.col[m] = split_jet(pj.col[m]);
       unsigned* base = sE + (f_local * C1) * RW + p_local * 2;
@@ -636,9 +663,9 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
     for (int64_t pb = pbeg; pb < pend; pb += 16) {
       // past the end of the chunk: any valid rows, fetched (and expanded) but never used
       const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
-      bf16x3_step<C1, ACT>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
+      bf16x3_step<C1, FE, ACT, GEN>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
                            gb + p2 * gstride, xoff, goff, lane, O);
-      bf16x3_step<C1, ACT>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
+      bf16x3_step<C1, FE, ACT, GEN>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
                            gb + p3 * gstride, xoff, goff, lane, O);
     }
   }
@@ -1011,11 +1038,12 @@ void launch_fwd_mfma(const LayerView& L, const float* a, const float* wt, float*
   else fwd_launch<9, 4>(L, a, wt, y, N, st);
 }
 
-// split-bf16 weight gradients: grid 10 (8 features x 14 columns = 7 column tiles).  The kernel walks whole pairs of
+// split-bf16 weight gradients: grid 10 (8 features x 14 columns = 7 column tiles per wave) and grid 20 (4 features
+// x 24 columns = 6 column tiles).  The kernel walks whole pairs of
 // 8-point steps; when N is not a multiple of 16 the last N % 16 points go to the fp32 kernel as a chunk of their own
 // (so at least two chunks are needed).
 bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N) {
-  if (!mfma_eligible(D, D2, L) || L.G != 10 || N < 16 || !L.ginfo) return false;
+  if (!mfma_eligible(D, D2, L) || (L.G != 10 && L.G != 20) || N < 16 || !L.ginfo) return false;
   if (N % 16 != 0 && mfma_weight_chunks(N, L) < 2) return false;
   const char* off = getenv("PDEKAN_DISABLE_BF16X3");    // A/B switch for tests and profiling
   return !(off && off[0] == '1');
@@ -1038,18 +1066,25 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
                                                        nchunks, 0);
     return;
   }
-  if constexpr (C1 % 2 == 0 && KIW == 8 && PB == 8) {
-    // points [0, N16) in nmain chunks: every block of 32 features goes to exactly one of the two kernels
+  if constexpr (C1 % 2 == 0 && (KIW == 8 || KIW == 4) && PB == 8) {
+    // points [0, N16) in nmain chunks: every block of 4 * KIW features goes to exactly one of the two kernels
     const int64_t N16 = N / 16 * 16, tail = N - N16;
     const int nmain = tail ? nchunks - 1 : nchunks;
     int64_t chunk = (N16 + nmain - 1) / nmain;
     chunk = (chunk + 15) / 16 * 16;
     k<<<(unsigned)(nx * ny * nmain), 256, lds, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, L.act, chunk, nx, ny,
                                                      nmain, 1);
-    auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, kActSiLU> : bwd_weight_bf16x3_kernel<C1, kActIdentity>;
-    const size_t lds_b = (size_t)4 * (3 * 8 * C1 * kBf16Rw + 8 * kKnotPad) * 4;
+    // both variants on the same grid: a block runs in the one that matches its features' knot rows
+    auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, KIW, kActSiLU, false>
+                                  : bwd_weight_bf16x3_kernel<C1, KIW, kActIdentity, false>;
+    auto kg = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, KIW, kActSiLU, true>
+                                  : bwd_weight_bf16x3_kernel<C1, KIW, kActIdentity, true>;
+    const size_t lds_b = (size_t)4 * (3 * KIW * C1 * kBf16Rw + KIW * kKnotPad) * 4;
+    const size_t lds_g = (size_t)4 * (3 * KIW * C1 * kBf16Rw + KIW * kKnotPadGen) * 4;
     allow_big_lds(kb, lds_b);
+    allow_big_lds(kg, lds_g);
     kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain);
+    kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain);
     if (tail)                                            // the last chunk slot: the points past N16, fp32 kernel, all blocks
       k<<<(unsigned)(nx * ny), 256, lds, st>>>(a4 + (size_t)N16 * L.I, g4 + (size_t)N16 * L.O, L.grid, L.ginfo,
                                                part + (size_t)nmain * L.packed_floats(), tail, L.I, L.O, L.act, 16, nx, ny,
@@ -1060,7 +1095,7 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
                             hipStream_t st, bool with_bf16x3) {
   if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3);
-  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st);
+  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3);
   else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
 }
 

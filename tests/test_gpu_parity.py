@@ -384,14 +384,16 @@ def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
 
 
 def test_split_bf16_and_fp32_blocks_share_one_layer():
-    """A 64-input layer whose features 32..63 have a moved knot: their block of 32 features takes the fp32 matrix
-    kernel with the general basis path, features 0..31 the split-bf16 kernel, in the same launch pair."""
-    m = _random_model([2, 64, 64, 1], 10, 90)
+    """A 96-input layer with three kinds of knot rows: features 0..31 equally spaced (split-bf16 kernel, polynomial
+    pieces), 32..63 with a knot moved by h/100 (split-bf16 kernel, general triangle around the quotient guess),
+    64..95 with a knot moved by 0.35 h (fp32 matrix kernel, interval search), all in the same launch group."""
+    m = _random_model([2, 96, 64, 1], 10, 90)
     with torch.no_grad():
-        m.layers[1].grid[32:, 7] += 2e-3
+        m.layers[1].grid[32:64, 7] += 2e-3
         m.layers[1].grid[40, 3] -= 1e-3
+        m.layers[1].grid[64:, 7] += 0.07
     x = _points_clear_of_knots(m, 2048, "silu", 91)
-    _grads_vs_oracle(m, x, "silu", [2, 64, 64, 1])
+    _grads_vs_oracle(m, x, "silu", [2, 96, 64, 1])
 
 
 @pytest.mark.parametrize("widths,G,N", [([600, 2, 1], 5, 7), ([3000, 2, 1], 5, 1), ([300, 3, 1], 64, 5)])
@@ -557,18 +559,28 @@ def test_fused_step_replays_from_a_hip_graph():
         assert torch.equal(step.flat_grad, grad_g)
 
 
-@pytest.mark.parametrize("I,O,N", [(32, 64, 48), (96, 64, 1000), (128, 128, 4112), (256, 256, 1000), (64, 256, 2064),
-                                   (32, 128, 16)])
-def test_split_bf16_weight_gradients_over_layer_shapes(I, O, N, monkeypatch):
-    """One grid-10 layer at a time through the layer-level entry points (jet forward + backward with a random
+@pytest.mark.parametrize("I,O,N,G,knots", [
+    (32, 64, 48, 10, "default"), (96, 64, 1000, 10, "default"), (128, 128, 4112, 10, "default"),
+    (256, 256, 1000, 10, "default"), (64, 256, 2064, 10, "default"), (32, 128, 16, 10, "default"),
+    (32, 64, 48, 20, "exact"), (48, 64, 1000, 20, "exact"), (256, 256, 2064, 20, "default"),
+    (64, 128, 4099, 20, "default"), (32, 64, 64, 20, "default"), (64, 64, 1000, 10, "moved")])
+def test_split_bf16_weight_gradients_over_layer_shapes(I, O, N, G, knots, monkeypatch):
+    """One grid-10 or grid-20 layer at a time through the layer-level entry points (jet forward + backward with a random
     cotangent): every block / chunk decode of the split-bf16 weight-gradient kernel (1 to 8 feature blocks, 1 to 4
-    output tiles, ragged N with the fp32 tail chunk) against the fp32 matrix kernel on the same inputs."""
+    output tiles, ragged N with the fp32 tail chunk) against the fp32 matrix kernel on the same inputs.  Knot rows:
+    the default grid 10 is equally spaced (polynomial pieces), the default grid 20 rounds its knots 1.5e-6 h off
+    (the kernel's general-knot variant), "exact" = grid 20 on [-1.25, 1.25], h = 1/8 (polynomial pieces again),
+    "moved" = a grid-10 row with two knots moved by up to h/20 (general-knot variant)."""
     from pde_amd.kan import KANLinear
     torch.manual_seed(I + O)
-    lay = KANLinear(I, O, grid_size=10).cuda()
+    lay = KANLinear(I, O, grid_size=G, grid_range=[-1.25, 1.25] if knots == "exact" else [-1, 1]).cuda()
+    if knots == "moved":
+        with torch.no_grad():
+            lay.grid[:, 5] += 0.01
+            lay.grid[::3, 9] -= 0.004
     g = torch.Generator().manual_seed(N)
     xj = torch.randn(N, I, 4, generator=g)
-    xj[:, :, 0] = torch.rand(N, I, generator=g) * 3.6 - 1.8          # also outside the grid [-1.6, 1.6]
+    xj[:, :, 0] = torch.rand(N, I, generator=g) * 3.6 - 1.8          # also outside the extended grid
     gy = torch.randn(N, O, 4, generator=g).cuda()
     xj = xj.cuda()
     grads = []
@@ -583,6 +595,8 @@ def test_split_bf16_weight_gradients_over_layer_shapes(I, O, N, monkeypatch):
     # heavy-tailed random jets: each kernel's fp32 accumulation alone sits 1e-6 to 3e-6 from an fp64 sum here
     for a, b in zip(*grads):
         assert max_rel(a.cpu(), b.cpu()) <= 5e-6
+    # the two kernels sum in different orders: bit-identical results would mean the switch selected nothing
+    assert not torch.equal(grads[0][1], grads[1][1])
     x = xj.double().cpu()
     x0, sg = x[..., 0], torch.sigmoid(x[..., 0])
     f0, f1, f2 = x0 * sg, sg * (1 + x0 * (1 - sg)), sg * (1 - sg) * (2 + x0 * (1 - 2 * sg))

@@ -165,6 +165,64 @@ def test_quotient_interval_path_matches_up_to_the_second_derivative(hm, G):
     assert worst < 4e-6, worst
 
 
+def test_knot_spacing_classes(hm):
+    """1/h for equally spaced rows, -1/h for rows within h/4 of equal spacing (the default grid of size 20, a
+    jittered grid), 0 for anything further off or not increasing."""
+    hm.hm_knot_spacing_info.restype = ctypes.c_float
+    for G, sign in ((5, 1), (10, 1), (20, -1)):
+        knots = O.uniform_grid(1, G)[0].numpy().copy()
+        v = hm.hm_knot_spacing_info(fptr(knots), len(knots))
+        assert np.sign(v) == sign and abs(abs(v) - G / 2.0) < 1e-4, (G, v)
+    rng = np.random.default_rng(3)
+    knots = O.uniform_grid(1, 10)[0].numpy().copy()
+    jit = (knots + rng.uniform(-0.2, 0.2, len(knots)) * 0.2).astype(np.float32)
+    jit[0], jit[-1] = knots[0], knots[-1]
+    assert hm.hm_knot_spacing_info(fptr(jit), len(jit)) < 0
+    far = knots.copy(); far[7] += 0.3 * 0.2
+    assert hm.hm_knot_spacing_info(fptr(far), len(far)) == 0.0
+    tied = knots.copy(); tied[7] = tied[8]
+    assert hm.hm_knot_spacing_info(fptr(tied), len(tied)) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["default20", "default10", "jittered"])
+def test_near_uniform_path_matches_dense_cox_de_boor(hm, kind):
+    """eval_basis_near_uniform (8 knots around the quotient guess, interval settled in registers, general triangle)
+    against dense Cox-de Boor in fp64 on the same fp32 knots: B, B', B'' everywhere, knots and their fp32
+    neighbours included, and the reference's half-open interval convention."""
+    G = 20 if kind == "default20" else 10
+    knots = O.uniform_grid(1, G)[0].numpy().copy()
+    h = 2.0 / G
+    if kind == "jittered":
+        rng = np.random.default_rng(5)
+        inner = knots[1:-1] + (rng.uniform(-0.2, 0.2, len(knots) - 2) * h).astype(np.float32)
+        knots = np.concatenate([knots[:1], inner, knots[-1:]]).astype(np.float32)
+    C = G + 3
+    around = np.concatenate([np.nextafter(knots, -np.inf), knots, np.nextafter(knots, np.inf)])
+    xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 3001), around,
+                         [-7.0, 9.0, 1e30, -1e30, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    ref = dense_reference(knots, xs, C, orders=3)
+    hmin = np.diff(knots.astype(np.float64)).min()
+    scale = np.array([1.0, 1 / hmin, 1 / hmin ** 2])[:, None]
+    b = np.zeros(16, np.float32)
+    cb, ib = ctypes.c_int(), ctypes.c_int()
+    worst = 0.0
+    for n, x in enumerate(xs):
+        hm.hm_eval_basis_near_uniform(fptr(knots), len(knots), ctypes.c_float(x), fptr(b), ctypes.byref(cb),
+                                      ctypes.byref(ib))
+        assert ib.value == int(knots[0] <= x < knots[-1])
+        if not ib.value:
+            assert not b.any()
+            continue
+        s = cb.value + 3
+        assert knots[s] <= x < knots[s + 1]
+        dense = np.zeros((3, C))
+        for m in range(4):
+            if 0 <= cb.value + m < C:
+                dense[:, cb.value + m] = b[m:12:4]
+        worst = max(worst, np.abs((dense - ref[:3, n]) / scale).max())
+    assert worst < (4e-6 if kind != "jittered" else 1.5e-5), worst
+
+
 def test_local_basis_nonuniform_knots(hm):
     rng = np.random.default_rng(0)
     knots = np.sort(rng.uniform(-2, 2, 12)).astype(np.float32)
