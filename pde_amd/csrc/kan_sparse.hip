@@ -54,6 +54,24 @@ __global__ void pack_window_kernel(const float* __restrict__ wp, float* __restri
   }
 }
 
+// wp[O][I][C1] -> raw[I][O][32] = {0, 0, 0, the C spline weights, 0 ...}: the 4 weights live on knot interval s are
+// the floats s .. s+3 of the row (kRawRow >= G + 10), wbt[I][O]
+constexpr int kRawRow = 32;
+__global__ void pack_raw_rows_kernel(const float* __restrict__ wp, float* __restrict__ raw,
+                                     float* __restrict__ wbt, int I, int O, int C) {
+  const int C1 = C + 1;
+  const int total = I * O * kRawRow;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int col = t % kRawRow;
+    const int o = (t / kRawRow) % O;
+    const int i = t / (kRawRow * O);
+    const float* w = wp + ((size_t)o * I + i) * C1;
+    const int c = col - 3;
+    raw[t] = (c >= 0 && c < C) ? w[c] : 0.0f;
+    if (col == 0) wbt[(size_t)i * O + o] = w[C];
+  }
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // acc += v * w.x  /  acc += v * w.y  on a register pair (two fp32 lanes per instruction).
@@ -83,7 +101,7 @@ struct Live {
   int slot;              // interval index s, clamped to [0, kSlots)
 };
 
-template <bool kNeedD3>
+template <bool kNeedD3, int kMaxSlot = kSlots - 1>
 __device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_kind, float x) {
   Basis bs;
   eval_basis_row<kNeedD3>(knots, nk, x, bs);
@@ -92,7 +110,7 @@ __device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_ki
   for (int m = 0; m < 4; ++m) { L.b[m] = bs.b[m]; L.d1[m] = bs.d1[m]; L.d2[m] = bs.d2[m]; L.d3[m] = bs.d3[m]; }
   L.act = eval_act(act_kind, x);
   int s = bs.c0 + 3;
-  s = s < 0 ? 0 : (s > kSlots - 1 ? kSlots - 1 : s);
+  s = s < 0 ? 0 : (s > kMaxSlot ? kMaxSlot : s);
   L.slot = s;
   return L;
 }
@@ -102,18 +120,29 @@ __device__ __forceinline__ Live eval_live(const float* knots, int nk, int act_ki
 // weights): a straight copy, so the four waves move it with LDS-DMA loads, one
 // KiB per instruction, no registers involved.  Retired by the next barrier_after_dma().
 // --------------------------------------------------------------------------
-template <int O>
+// RS = floats per output in the table: 64 (window table, 16 slots x 4) or kRawRow (raw rows).  The block takes the
+// O outputs from o0 of a layer with OT outputs (tables are [I][OT][RS], base weights [I][OT]).
+template <int O, int RS = 64>
 __device__ __forceinline__ void table_stage(float* sT, float* sB, const float* win, const float* wbt, int i, int wave,
-                                            int lane) {
-  const float* src = win + (size_t)i * O * 64 + wave * (O * 16);
-  float* dst = sT + wave * (O * 16);
+                                            int lane, int OT = O, int o0 = 0) {
+  static_assert((O * RS) % 1024 == 0, "each wave copies whole 1 KiB pieces");
+  const float* src = win + ((size_t)i * OT + o0) * RS + wave * (O * RS / 4);
+  float* dst = sT + wave * (O * RS / 4);
 #pragma unroll
-  for (int k = 0; k < O / 16; ++k)
+  for (int k = 0; k < O * RS / 1024; ++k)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 256 + lane * 4),
                                      (__attribute__((address_space(3))) void*)(dst + k * 256), 16, 0, 0);
   if (wave < O / 64)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbt + (size_t)i * O + wave * 64 + lane),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbt + (size_t)i * OT + o0 + wave * 64 + lane),
                                      (__attribute__((address_space(3))) void*)(sB + wave * 64), 4, 0, 0);
+}
+
+// the 4 live spline weights of one output: one 16-byte read of its window slot, or 4 floats from its raw row at
+// any 4-byte offset (two ds_read2_b32)
+template <int RS>
+__device__ __forceinline__ f32x4 live_weights(const float* row) {
+  if constexpr (RS == 64) return *reinterpret_cast<const f32x4*>(row);
+  else return (f32x4){row[0], row[1], row[2], row[3]};
 }
 
 // --------------------------------------------------------------------------
@@ -169,17 +198,20 @@ __device__ __forceinline__ void jets_stage(float* sJ, const float* a, const Wave
 // ==========================================================================
 // forward
 // ==========================================================================
-template <int O, int FS>
+template <int O, int FS, int RS = 64>
 __global__ void __launch_bounds__(256, 2)
 fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                   const float* __restrict__ win,
-                  const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act) {
+                  const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act, int OTr) {
   constexpr int OG = O / 32;              // output groups = lanes per point
   constexpr int PW = 64 / OG;             // points per wave
+  constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
+  const int OT = (RS == 64) ? O : OTr;    // raw rows: blockIdx.y picks the block's O of the layer's OT outputs
+  const int o0 = (RS == 64) ? 0 : (int)blockIdx.y * O;
   const int nk = G + 7;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sT = reinterpret_cast<float*>(smem);            // [2][O*64]
-  float* sB = sT + 2 * O * 64;                           // [2][O]
+  float* sT = reinterpret_cast<float*>(smem);            // [2][O*RS]
+  float* sB = sT + 2 * O * RS;                           // [2][O]
   float* sJ = sB + 2 * O;                                // [4 waves][2][PW][FS][4] staged input jets
   float* sK = sJ + 4 * 2 * PW * FS * 4;                 // [I][kKnotPadS]
 
@@ -196,7 +228,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
+  table_stage<O, RS>(sT, sB, win, wbt, 0, wave, lane, OT, o0);
   jets_stage<PW, FS>(sJw, a, wr, I, 0);
 
   f32x2 accl[32], acch[32];               // jets (0,1) and (2,3) of the lane's 32 outputs
@@ -208,11 +240,12 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   // weight reads go out right after it.
   barrier_after_dma();                     // knots, table 0, jets of features 0..3
   f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * FS) * 4);
-  Live L = eval_live<false>(sK, nk, act, cur[0]);
+  Live L = eval_live<false, kMaxSlot>(sK, nk, act, cur[0]);
 
   for (int i = 0; i < I; ++i) {
     const int buf = i & 1;
-    if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
+    if (i + 1 < I)
+      table_stage<O, RS>(sT + (buf ^ 1) * O * RS, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane, OT, o0);
     if ((i % FS) == 0 && i + FS < I)     // features i+4..i+7 into the other staging buffer
       jets_stage<PW, FS>(sJw + (((i / FS) + 1) & 1) * PW * FS * 4, a, wr, I, i + FS);
     const float s2 = cur[1] * cur[1];
@@ -225,14 +258,14 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     }
     el[4] = (f32x2){L.act.f0, L.act.f1 * cur[1]};
     eh[4] = (f32x2){L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
-    const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
+    const float* tb = sT + buf * O * RS + (g * 32) * RS + L.slot * (RS == 64 ? 4 : 1);
     const float* bb = sB + buf * O + g * 32;
     // outputs in groups of 4; the weights of group q+2 are read from LDS while group q is consumed
     f32x4 wq[3][4], bq[3];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) wq[r][k] = *reinterpret_cast<const f32x4*>(tb + (r * 4 + k) * 64);
+      for (int k = 0; k < 4; ++k) wq[r][k] = live_weights<RS>(tb + (r * 4 + k) * RS);
       bq[r] = *reinterpret_cast<const f32x4*>(bb + r * 4);
     }
 #pragma unroll
@@ -240,7 +273,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
       const int cq = q % 3, nxt = (q + 2) % 3;
       if (q + 2 < 8) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wq[nxt][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 2) * 4 + k) * 64);
+        for (int k = 0; k < 4; ++k) wq[nxt][k] = live_weights<RS>(tb + ((q + 2) * 4 + k) * RS);
         bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 2) * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -261,7 +294,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     if (i + 1 < I) {
       const int n = i + 1;
       cur = *reinterpret_cast<const f32x4*>(sJw + (((n / FS) & 1) * PW * FS + pl * FS + (n % FS)) * 4);
-      L = eval_live<false>(sK + n * kKnotPadS, nk, act, cur[0]);
+      L = eval_live<false, kMaxSlot>(sK + n * kKnotPadS, nk, act, cur[0]);
       barrier_after_dma();                 // table i+1 landed everywhere; table i no longer read
     }
   }
@@ -271,7 +304,8 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   __syncthreads();                                       // every wave is done with the tables
   constexpr int LS = 36;                                 // floats per parked line: 32 + 4 pad (bank spread)
   float* park = sT + wave * (64 * LS);                   // 64 lines per wave and pass; spans sT, sB and sJ
-  static_assert(4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * FS * 4, "parking area fits the staging buffers");
+  // (raw rows: also the head of the knot rows, dead by now; the launcher sizes the allocation for it)
+  static_assert(RS != 64 || 4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * FS * 4, "parking area fits the staging buffers");
   const int line_w = pl * OG + g;                        // the line this lane fills: (point, output group)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -285,7 +319,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
       const int line = (lane >> 3) + 8 * r, j = lane & 7;
       const f32x4 v = *reinterpret_cast<const f32x4*>(park + line * LS + j * 4);
       const int64_t pp = P0 + line / OG;
-      if (pp < N) *reinterpret_cast<f32x4*>(y + (pp * O + (line % OG) * 32 + 8 * k + j) * 4) = v;
+      if (pp < N) *reinterpret_cast<f32x4*>(y + (pp * OT + o0 + (line % OG) * 32 + 8 * k + j) * 4) = v;
     }
   }
 }
@@ -293,17 +327,21 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
 // ==========================================================================
 // input-jet gradients
 // ==========================================================================
-template <int O>
+template <int O, int RS = 64>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
                         const float* __restrict__ ginfo, const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
-                        int64_t N, int I, int G, int act) {
+                        int64_t N, int I, int G, int act, int OTr) {
   constexpr int OG = O / 32;
   constexpr int PW = 64 / OG;
+  constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
+  // raw rows: the layer's OT outputs are walked O at a time, each pass adding its share to the input gradients
+  const int OT = (RS == 64) ? O : OTr;
+  const int npass = (RS == 64) ? 1 : OTr / O;
   const int nk = G + 7;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);
-  float* sB = sT + 2 * O * 64;
+  float* sB = sT + 2 * O * RS;
   float* sJ = sB + 2 * O;                                // [4 waves][2][PW][kFS][4] staged input jets
   float* sO = sJ + 4 * 2 * PW * kFS * 4;                 // [4 waves][PW][kFS][4] staged output gradients
   float* sK = sO + 4 * PW * kFS * 4;
@@ -318,12 +356,16 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   float* sOw = sO + wave * PW * kFS * 4;
   // write the kFS gradients parked for features i0..i0+3: 4 lanes store the 64 contiguous bytes of a point
   const WaveRows<PW> wr = wave_rows<PW>(P0, N, I, lane);
-  auto flush_out = [&](int i0) {
+  auto flush_out = [&](int i0, bool add) {
     float* dst = ga + (wr.base * I + i0) * 4;
 #pragma unroll
     for (int k = 0; k < WaveRows<PW>::NV; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sOw + (lane + 64 * k) * 4);
-      if ((lane + 64 * k) / kFS < wr.nlive) *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sOw + (lane + 64 * k) * 4);
+      if ((lane + 64 * k) / kFS < wr.nlive) {
+        // a later pass adds to what this same lane stored at this address in the pass before
+        if (RS != 64 && add) v += *reinterpret_cast<const f32x4*>(dst + wr.off[k]);
+        *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
+      }
     }
   };
 
@@ -331,123 +373,136 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
     const int f = t / (nk + 1), k = t - f * (nk + 1);
     sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  // cotangents of this lane's 32 outputs stay in registers for the whole kernel.  They are 512
-  // contiguous bytes per lane in gy; fetched as whole 128-byte lines (8 lanes per line) and handed to
-  // their lanes through LDS, 8 outputs at a time (the staging buffers are still unused here).
-  f32x2 gyl[32], gyh[32];
-  {
-    constexpr int LS = 36;                               // floats per parked line: 32 + 4 pad (bank spread)
-    float* park = sT + wave * (64 * LS);
-    static_assert(4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * kFS * 4, "parking area fits the staging buffers");
-    const int line_w = pl * OG + g;                      // the line this lane consumes: (point, output group)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int line = (lane >> 3) + 8 * r, j = lane & 7;
-        int64_t pp = P0 + line / OG;
-        if (pp > N - 1) pp = N - 1;
-        *reinterpret_cast<f32x4*>(park + line * LS + j * 4) =
-            *reinterpret_cast<const f32x4*>(gy + (pp * O + (line % OG) * 32 + 8 * k + j) * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(park + line_w * LS + j * 4);
-        gyl[8 * k + j] = lo2(v); gyh[8 * k + j] = hi2(v);
-      }
-    }
-  }
-  __syncthreads();                                       // parking area released before the tables land in it
-  table_stage<O>(sT, sB, win, wbt, 0, wave, lane);
-  jets_stage<PW>(sJw, a, wr, I, 0);
-
-  // as in the forward kernel, the basis of feature i+1 is evaluated before the barrier that ends iteration i
-  barrier_after_dma();
-  f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * kFS) * 4);
-  Live L = eval_live<true>(sK, nk, act, cur[0]);
-
-  for (int i = 0; i < I; ++i) {
-    const int buf = i & 1;
-    if (i + 1 < I) table_stage<O>(sT + (buf ^ 1) * O * 64, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane);
-    if ((i % kFS) == 0) {
-      if (i > 0) flush_out(i - kFS);       // gradients of the previous 4 features, parked before the barrier
-      if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
-    }
-    const float* tb = sT + buf * O * 64 + (g * 32) * 64 + L.slot * 4;
-    const float* bb = sB + buf * O + g * 32;
-    f32x2 Gl[5], Gh[5];                    // per live column: sums over outputs of w * cotangent, jets (0,1) | (2,3)
-#pragma unroll
-    for (int m = 0; m < 5; ++m) { Gl[m] = (f32x2){0.f, 0.f}; Gh[m] = (f32x2){0.f, 0.f}; }
-    f32x4 wq[2][4], bq[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(tb + k * 64);
-    bq[0] = *reinterpret_cast<const f32x4*>(bb);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int cw = q & 1, nw = cw ^ 1;
-      if (q + 1 < 8) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wq[nw][k] = *reinterpret_cast<const f32x4*>(tb + ((q + 1) * 4 + k) * 64);
-        bq[nw] = *reinterpret_cast<const f32x4*>(bb + (q + 1) * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+  for (int pass = 0; pass < npass; ++pass) {
+    const int o0 = pass * O;
+    if (pass > 0) __syncthreads();                       // every wave is done with the previous pass's tables
+    // cotangents of this lane's 32 outputs stay in registers for the whole kernel.  They are 512
+    // contiguous bytes per lane in gy; fetched as whole 128-byte lines (8 lanes per line) and handed to
+    // their lanes through LDS, 8 outputs at a time (the staging buffers are still unused here).
+    f32x2 gyl[32], gyh[32];
+    {
+      constexpr int LS = 36;                               // floats per parked line: 32 + 4 pad (bank spread)
+      float* park = sT + wave * (64 * LS);
+      static_assert(4 * 64 * LS <= 2 * O * RS + 2 * O + 4 * 2 * PW * kFS * 4 + 4 * PW * kFS * 4,
+                    "parking area fits the staging buffers (it ends before the knot rows)");
+      const int line_w = pl * OG + g;                      // the line this lane consumes: (point, output group)
+  #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x2 w01 = lo2(wq[cw][k]), w23 = hi2(wq[cw][k]);
-        const f32x2 wb = (k < 2) ? lo2(bq[cw]) : hi2(bq[cw]);
-        const f32x2 vl = gyl[q * 4 + k], vh = gyh[q * 4 + k];
-        pkfma_x(Gl[0], vl, w01); pkfma_x(Gh[0], vh, w01);
-        pkfma_y(Gl[1], vl, w01); pkfma_y(Gh[1], vh, w01);
-        pkfma_x(Gl[2], vl, w23); pkfma_x(Gh[2], vh, w23);
-        pkfma_y(Gl[3], vl, w23); pkfma_y(Gh[3], vh, w23);
-        if (k & 1) { pkfma_y(Gl[4], vl, wb); pkfma_y(Gh[4], vh, wb); }
-        else       { pkfma_x(Gl[4], vl, wb); pkfma_x(Gh[4], vh, wb); }
+  #pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int line = (lane >> 3) + 8 * r, j = lane & 7;
+          int64_t pp = P0 + line / OG;
+          if (pp > N - 1) pp = N - 1;
+          *reinterpret_cast<f32x4*>(park + line * LS + j * 4) =
+              *reinterpret_cast<const f32x4*>(gy + (pp * OT + o0 + (line % OG) * 32 + 8 * k + j) * 4);
+        }
+  #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(park + line_w * LS + j * 4);
+          gyl[8 * k + j] = lo2(v); gyh[8 * k + j] = hi2(v);
+        }
       }
     }
-    // chain rule on this lane's partial sums (linear in G, so it commutes with the sum over groups)
-    const float s2 = cur[1] * cur[1];
-    f32x4 out = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      const float e1 = m < 4 ? L.d1[m & 3] : L.act.f1;
-      const float e2 = m < 4 ? L.d2[m & 3] : L.act.f2;
-      const float e3 = m < 4 ? L.d3[m & 3] : L.act.f3;
-      const f32x4 q = {Gl[m][0], Gl[m][1], Gh[m][0], Gh[m][1]};
-      out[0] += q[0] * e1 + (q[1] * cur[1] + q[2] * cur[2]) * e2 + q[3] * (s2 * e3 + cur[3] * e2);
-      out[1] += q[1] * e1 + 2.0f * cur[1] * q[3] * e2;
-      out[2] += q[2] * e1;
-      out[3] += q[3] * e1;
+    __syncthreads();                                       // parking area released before the tables land in it
+    table_stage<O, RS>(sT, sB, win, wbt, 0, wave, lane, OT, o0);
+    jets_stage<PW>(sJw, a, wr, I, 0);
+
+    // as in the forward kernel, the basis of feature i+1 is evaluated before the barrier that ends iteration i
+    barrier_after_dma();
+    f32x4 cur = *reinterpret_cast<const f32x4*>(sJw + (pl * kFS) * 4);
+    Live L = eval_live<true, kMaxSlot>(sK, nk, act, cur[0]);
+
+    for (int i = 0; i < I; ++i) {
+      const int buf = i & 1;
+      if (i + 1 < I)
+        table_stage<O, RS>(sT + (buf ^ 1) * O * RS, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane, OT, o0);
+      if ((i % kFS) == 0) {
+        if (i > 0) flush_out(i - kFS, pass > 0);   // gradients of the previous 4 features, parked before the barrier
+        if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
+      }
+      const float* tb = sT + buf * O * RS + (g * 32) * RS + L.slot * (RS == 64 ? 4 : 1);
+      const float* bb = sB + buf * O + g * 32;
+      f32x2 Gl[5], Gh[5];                    // per live column: sums over outputs of w * cotangent, jets (0,1) | (2,3)
+  #pragma unroll
+      for (int m = 0; m < 5; ++m) { Gl[m] = (f32x2){0.f, 0.f}; Gh[m] = (f32x2){0.f, 0.f}; }
+      f32x4 wq[2][4], bq[2];
+  #pragma unroll
+      for (int k = 0; k < 4; ++k) wq[0][k] = live_weights<RS>(tb + k * RS);
+      bq[0] = *reinterpret_cast<const f32x4*>(bb);
+  #pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cw = q & 1, nw = cw ^ 1;
+        if (q + 1 < 8) {
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) wq[nw][k] = live_weights<RS>(tb + ((q + 1) * 4 + k) * RS);
+          bq[nw] = *reinterpret_cast<const f32x4*>(bb + (q + 1) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x2 w01 = lo2(wq[cw][k]), w23 = hi2(wq[cw][k]);
+          const f32x2 wb = (k < 2) ? lo2(bq[cw]) : hi2(bq[cw]);
+          const f32x2 vl = gyl[q * 4 + k], vh = gyh[q * 4 + k];
+          pkfma_x(Gl[0], vl, w01); pkfma_x(Gh[0], vh, w01);
+          pkfma_y(Gl[1], vl, w01); pkfma_y(Gh[1], vh, w01);
+          pkfma_x(Gl[2], vl, w23); pkfma_x(Gh[2], vh, w23);
+          pkfma_y(Gl[3], vl, w23); pkfma_y(Gh[3], vh, w23);
+          if (k & 1) { pkfma_y(Gl[4], vl, wb); pkfma_y(Gh[4], vh, wb); }
+          else       { pkfma_x(Gl[4], vl, wb); pkfma_x(Gh[4], vh, wb); }
+        }
+      }
+      // chain rule on this lane's partial sums (linear in G, so it commutes with the sum over groups)
+      const float s2 = cur[1] * cur[1];
+      f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const float e1 = m < 4 ? L.d1[m & 3] : L.act.f1;
+        const float e2 = m < 4 ? L.d2[m & 3] : L.act.f2;
+        const float e3 = m < 4 ? L.d3[m & 3] : L.act.f3;
+        const f32x4 q = {Gl[m][0], Gl[m][1], Gh[m][0], Gh[m][1]};
+        out[0] += q[0] * e1 + (q[1] * cur[1] + q[2] * cur[2]) * e2 + q[3] * (s2 * e3 + cur[3] * e2);
+        out[1] += q[1] * e1 + 2.0f * cur[1] * q[3] * e2;
+        out[2] += q[2] * e1;
+        out[3] += q[3] * e1;
+      }
+      // add the output groups of one point (lanes pl, pl+PW, ...)
+      if (PW == 16) {
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = sum_xor16(out[j]);
+      }
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = sum_xor32(out[j]);
+      if (g == 0) *reinterpret_cast<f32x4*>(sOw + (pl * kFS + (i % kFS)) * 4) = out;
+      if (i + 1 < I) {
+        const int n = i + 1;
+        cur = *reinterpret_cast<const f32x4*>(sJw + (((n / kFS) & 1) * PW * kFS + pl * kFS + (n % kFS)) * 4);
+        L = eval_live<true, kMaxSlot>(sK + n * kKnotPadS, nk, act, cur[0]);
+        barrier_after_dma();
+      }
     }
-    // add the output groups of one point (lanes pl, pl+PW, ...)
-    if (PW == 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[j] = sum_xor16(out[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = sum_xor32(out[j]);
-    if (g == 0) *reinterpret_cast<f32x4*>(sOw + (pl * kFS + (i % kFS)) * 4) = out;
-    if (i + 1 < I) {
-      const int n = i + 1;
-      cur = *reinterpret_cast<const f32x4*>(sJw + (((n / kFS) & 1) * PW * kFS + pl * kFS + (n % kFS)) * 4);
-      L = eval_live<true>(sK + n * kKnotPadS, nk, act, cur[0]);
-      barrier_after_dma();
-    }
+    __syncthreads();
+    flush_out(I - kFS, pass > 0);
   }
-  __syncthreads();
-  flush_out(I - kFS);
 }
 
 // ==========================================================================
 // host side
 // ==========================================================================
+// Window tables (one aligned 16-byte LDS read per output) need G + 6 <= 16 slots and 64 or 128 outputs; every other
+// layer up to G = 20 and 256 outputs takes the raw-row tables (64 outputs per block, two ds_read2_b32 per output).
+static bool window_layout(const LayerView& L) { return L.G + 6 <= kSlots && (L.O == 64 || L.O == 128); }
+static bool raw_layout(const LayerView& L) {
+  return !window_layout(L) && L.G + 10 <= kRawRow && L.O % 64 == 0 && L.O <= 256 && L.I >= 8 && L.I % kFS == 0;
+}
+
 bool sparse_eligible(int D, int D2, const LayerView& L) {
   if (D != 2 || D2 != 1) return false;
   const char* off = getenv("PDEKAN_DISABLE_SPARSE");
   if (off && off[0] == '1') return false;
-  if (L.G + 6 > kSlots) return false;
-  if (L.O != 64 && L.O != 128) return false;
-  // the forward kernel stages 4 features of a point at a time, or 2 (64 outputs only)
   if (L.I < 2 || L.I > 256) return false;
+  if (raw_layout(L)) return true;
+  if (!window_layout(L)) return false;
+  // the forward kernel stages 4 features of a point at a time, or 2 (64 outputs only)
   return (L.I % 4 == 0) || (L.O == 64 && L.I % 2 == 0);
 }
 
@@ -456,20 +511,30 @@ bool sparse_input_grad_eligible(int D, int D2, const LayerView& L) {
   return sparse_eligible(D, D2, L) && L.I >= 8 && L.I % kFS == 0;
 }
 
-size_t sparse_table_floats(const LayerView& L) { return (size_t)L.I * L.O * (kSlots * 4 + 1); }
-
-void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st) {
-  const int total = L.I * L.O * kSlots;
-  int blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  pack_window_kernel<<<blocks, 256, 0, st>>>(wp, win, win + (size_t)L.I * L.O * kSlots * 4, L.I, L.O, L.C());
+size_t sparse_table_floats(const LayerView& L) {
+  return (size_t)L.I * L.O * ((window_layout(L) ? kSlots * 4 : kRawRow) + 1);
 }
 
-template <int O>
+void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st) {
+  const bool window = window_layout(L);
+  const int per = window ? kSlots : kRawRow;
+  const int total = L.I * L.O * per;
+  int blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  float* wbt = win + (size_t)L.I * L.O * (window ? kSlots * 4 : kRawRow);
+  if (window) pack_window_kernel<<<blocks, 256, 0, st>>>(wp, win, wbt, L.I, L.O, L.C());
+  else pack_raw_rows_kernel<<<blocks, 256, 0, st>>>(wp, win, wbt, L.I, L.O, L.C());
+}
+
+// dynamic LDS of a block: tables, base weights, staged jets (+ parked gradients), knot rows; never less than the
+// area the wide tensors are parked in on their way to / from registers (4 waves x 64 lines x 36 floats)
+template <int O, int RS = 64>
 static size_t sparse_lds(const LayerView& L, bool with_out_stage, int fs = kFS) {
   constexpr int PW = 64 / (O / 32);
-  return (size_t)(2 * O * 64 + 2 * O + 4 * 2 * PW * fs * 4 + (with_out_stage ? 4 * PW * fs * 4 : 0) +
-                  L.I * kKnotPadS) * 4;
+  const size_t floats = (size_t)(2 * O * RS + 2 * O + 4 * 2 * PW * fs * 4 + (with_out_stage ? 4 * PW * fs * 4 : 0) +
+                                 L.I * kKnotPadS);
+  const size_t park = 4 * 64 * 36;
+  return (floats > park ? floats : park) * 4;
 }
 
 template <typename Kern>
@@ -477,18 +542,21 @@ static void big_lds(Kern k, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int O, int FS>
+template <int O, int FS, int RS = 64>
 static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
-  const float* wbt = win + (size_t)L.I * L.O * kSlots * 4;
+  const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));               // points per block
-  auto k = fwd_sparse_kernel<O, FS>;
-  const size_t lds = sparse_lds<O>(L, false, FS);
+  auto k = fwd_sparse_kernel<O, FS, RS>;
+  const size_t lds = sparse_lds<O, RS>(L, false, FS);
   big_lds(k, lds);
-  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act);
+  const dim3 g((unsigned)((N + pts - 1) / pts), RS == 64 ? 1 : L.O / O);
+  k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O);
 }
 
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
-  if (L.O == 64) {
+  if (!window_layout(L)) {
+    fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st);
+  } else if (L.O == 64) {
     if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st);
     else fwd_sparse_launch<64, 2>(L, a, win, y, N, st);
   } else {
@@ -496,22 +564,22 @@ void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, flo
   }
 }
 
+template <int O, int RS = 64>
+static void bwd_input_sparse_launch(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
+                                    int64_t N, hipStream_t st) {
+  const float* wbt = win + (size_t)L.I * L.O * RS;
+  constexpr int pts = 4 * (64 / (O / 32));
+  auto k = bwd_input_sparse_kernel<O, RS>;
+  const size_t lds = sparse_lds<O, RS>(L, true);
+  big_lds(k, lds);
+  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O);
+}
+
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
                              int64_t N, hipStream_t st) {
-  const float* wbt = win + (size_t)L.I * L.O * kSlots * 4;
-  if (L.O == 64) {
-    const int pts = 4 * 32;
-    auto k = bwd_input_sparse_kernel<64>;
-    const size_t lds = sparse_lds<64>(L, true);
-    big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
-  } else {
-    const int pts = 4 * 16;
-    auto k = bwd_input_sparse_kernel<128>;
-    const size_t lds = sparse_lds<128>(L, true);
-    big_lds(k, lds);
-    k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act);
-  }
+  if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st);
+  else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st);
+  else bwd_input_sparse_launch<128>(L, a, gy, win, ga, N, st);
 }
 
 }  // namespace pdekan

@@ -383,6 +383,21 @@ def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
     assert max_rel(g_split.cpu(), step32.flat_grad.cpu()) <= 2e-6
 
 
+@pytest.mark.parametrize("sparse", ["1", "0"])
+@pytest.mark.parametrize("widths,G,N", [([2, 64, 64, 1], 20, 777), ([2, 32, 256, 64, 1], 20, 1040),
+                                        ([2, 64, 256, 64, 1], 10, 515), ([2, 128, 192, 1], 20, 130)])
+def test_raw_row_sparse_layers_match_oracle(widths, G, N, sparse, monkeypatch):
+    """Hidden layers the window tables do not take (grid 20: 26 intervals; 192 or 256 outputs) run the sparse
+    forward / input-gradient kernels on raw weight rows, 64 outputs per block; wider layers take several passes
+    over the outputs, each adding to the input gradients.  sparse = "0": the same models with the sparse kernels
+    switched off (dense matrix kernels, or streaming where those do not apply)."""
+    if sparse == "0":
+        monkeypatch.setenv("PDEKAN_DISABLE_SPARSE", "1")
+    m = _random_model(widths, G, 300 + N)
+    x = _points_clear_of_knots(m, N, "silu", 12)
+    _grads_vs_oracle(m, x, "silu", widths)
+
+
 def test_split_bf16_and_fp32_blocks_share_one_layer():
     """A 96-input layer with three kinds of knot rows: features 0..31 equally spaced (split-bf16 kernel, polynomial
     pieces), 32..63 with a knot moved by h/100 (split-bf16 kernel, general triangle around the quotient guess),
