@@ -17,6 +17,15 @@
 // the data.  The table of feature i+1 is staged (global -> registers -> LDS,
 // double-buffered) while feature i is being consumed.
 //
+// Layers the window tables do not fit (more than 16 knot intervals: grid 20; 192
+// or 256 outputs) keep the weights as raw rows [output][3 zeros, C weights,
+// zeros] (32 floats): the 4 live weights are floats s .. s+3 of the row, read
+// at 4-byte alignment (two ds_read2_b32: half the LDS rate of the aligned
+// read, a quarter of the table size).  A block then takes 64 of the layer's
+// outputs: the forward grid has one block row per 64 outputs, the
+// input-gradient kernel walks the outputs 64 at a time and adds each pass
+// into the gradients it stored in the pass before.
+//
 //   forward:      y[p][o][:]     += sum_m w[o][i][s-3+m] * E_m[:] + w_b[o][i] * E_b[:]
 //   input grads:  G_m[:]          = sum_o w[o][i][s-3+m] * gy[p][o][:]   (+ base), then the
 //                 chain rule through B', B'', B''' exactly as in the streaming kernel
