@@ -509,6 +509,7 @@ __device__ __forceinline__ float4 ld16(const char* __restrict__ row, unsigned of
   return *reinterpret_cast<const float4*>(row + off);
 }
 
+constexpr int kBf16FlushPoints = 512;        // points accumulated by the matrix instructions between two vector adds
 constexpr int kBf16Rw = 20;                  // words per E tile row: 32 bf16 + 16 bytes of pad (bank spread; dump slot)
 
 // One step = 8 points = NT regions of 24 matrix instructions (one column tile each; NT = 7 is described, NT = 6
@@ -618,11 +619,15 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
   const FeatureGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
                           fabsf(ginfo[i0 + f_local])};
 
-  f32x4 acc[NT][4];
+  // The matrix instruction's accumulate is not round-to-nearest: over a run of steps the running sums drift by an
+  // amount that grows with the length of the run (measured against fp64: 1.6e-5 of the gradient after 4096 points,
+  // 1.7e-6 after 512).  So the matrix instructions accumulate kBf16FlushPoints points at a time into acc, which
+  // is then added (vector add, round-to-nearest) into tot and cleared; tot is touched nowhere else.
+  f32x4 acc[NT][4], tot[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 4; ++m) { acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   // N and chunk_pts are multiples of 16: whole pairs of steps
   const int64_t pbeg = (int64_t)bz * chunk_pts;
@@ -660,13 +665,23 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
       for (int m = 0; m < 4; ++m) split_gy_tile(g0[m], GA, m);
     }
     TileOps cur = read_tile<COLS, RW>(sE + r * RW + q * 4, 0);
-    for (int64_t pb = pbeg; pb < pend; pb += 16) {
-      // past the end of the chunk: any valid rows, fetched (and expanded) but never used
-      const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
-      bf16x3_step<C1, FE, ACT, GEN>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p2 * xstride, gb + p1 * gstride,
-                           gb + p2 * gstride, xoff, goff, lane, O);
-      bf16x3_step<C1, FE, ACT, GEN>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p3 * xstride, gb + p2 * gstride,
-                           gb + p3 * gstride, xoff, goff, lane, O);
+    for (int64_t pb = pbeg; pb < pend;) {
+      const int64_t pstop = (pb + kBf16FlushPoints < pend) ? pb + kBf16FlushPoints : pend;
+      for (; pb < pstop; pb += 16) {
+        // past the end of the chunk: any valid rows, fetched (and expanded) but never used
+        const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
+        bf16x3_step<C1, FE, ACT, GEN>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p2 * xstride,
+                                      gb + p1 * gstride, gb + p2 * gstride, xoff, goff, lane, O);
+        bf16x3_step<C1, FE, ACT, GEN>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, prev_c0, xb + p3 * xstride,
+                                      gb + p2 * gstride, gb + p3 * gstride, xoff, goff, lane, O);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          tot[t][m] += acc[t][m];
+          acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
   }
   // D[row][output]: this lane holds columns 16t + 4q .. + 3 of output 16m + r
@@ -675,7 +690,7 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       float* dst = part + (((size_t)bz * O + o0 + m * 16 + r) * I + i0) * C1 + t * 16 + 4 * q;
-      *reinterpret_cast<f32x4*>(dst) = acc[t][m];
+      *reinterpret_cast<f32x4*>(dst) = tot[t][m];
     }
 }
 
@@ -1005,11 +1020,23 @@ bool mfma_eligible(int D, int D2, const LayerView& L) {
   return true;
 }
 
+// Chunks of points per weight-gradient launch: enough blocks to fill the chip, and short enough that a chunk's
+// running fp32 sums stay accurate (a 2^19-point chunk loses 3e-5 against an fp64 sum, an 8192-point one 4e-6; the
+// chunks themselves are added in 64 interleaved running sums by sum_partials_kernel), within 4 GiB of partial sums.
 int mfma_weight_chunks(int64_t N, const LayerView& L) {
   MfmaCfg c;
   cfg_for(L.G, c);
   const int per_chunk = (L.I / (4 * c.kiw)) * (L.O / 64);
   int64_t want = (512 + per_chunk - 1) / per_chunk;
+  int64_t chunk_pts = 8192;
+  if (const char* e = getenv("PDEKAN_WEIGHT_CHUNK_POINTS")) {          // experiments: 512 .. 2^20 points per chunk
+    const long v = atol(e);
+    if (v >= 512 && v <= (1 << 20)) chunk_pts = v;
+  }
+  const int64_t for_accuracy = (N + chunk_pts - 1) / chunk_pts;
+  if (want < for_accuracy) want = for_accuracy;
+  const int64_t fits = ((int64_t)4 << 30) / ((int64_t)L.packed_floats() * 4);
+  if (want > fits) want = fits;
   const int64_t cap = (N + 511) / 512;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -1110,6 +1137,8 @@ bool mfma_skinny_weight_eligible(int D, int D2, const LayerView& L) {
 
 int mfma_skinny_weight_chunks(int64_t N, const LayerView& L) {
   int64_t want = 768 / (L.O / 64);                      // three blocks per CU in flight (the register budget's limit)
+  const int64_t for_accuracy = (N + 16383) / 16384;     // a chunk's 4 waves keep running fp32 sums over a quarter of it each
+  if (want < for_accuracy) want = for_accuracy;
   const int64_t cap = (N + 255) / 256;
   if (want > cap) want = cap;
   if (want < 1) want = 1;

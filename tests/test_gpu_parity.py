@@ -326,18 +326,23 @@ def test_moved_grid_takes_the_general_basis_path():
             off += n
 
 
-def _points_clear_of_knots(m_cpu, n, act, seed, clearance=1e-6):
+def _points_clear_of_knots(m_cpu, n, act, seed, clearance=1e-6, device="cpu"):
     """Seeded points none of whose hidden activations sits within `clearance` of a knot of the next layer.
     The third derivative of a cubic B-spline jumps at the knots and enters the input gradients, so a value
     within fp32 rounding of a knot (it happens once in ~10^5 activations) makes the gradients of the layers
     below depend on which side the rounding falls: any fp32 implementation, the reference's included, can
     differ from the fp64 oracle there by the whole contribution of that point."""
-    layers = O.layers_from_state_dict(m_cpu.state_dict(), dtype=torch.float64)
+    layers = [{k: (v.to(device) if v is not None else None) for k, v in lay.items()}
+              for lay in O.layers_from_state_dict(m_cpu.state_dict(), dtype=torch.float64)]
     x = torch.rand(n + n // 8 + 16, m_cpu.layers[0].in_features, generator=torch.Generator().manual_seed(seed))
-    h, clear = x.double(), torch.ones(x.size(0), dtype=torch.bool)
-    for li in range(len(layers) - 1):
-        h = O.layer_forward(h, layers[li], act)
-        clear &= (h[:, :, None] - layers[li + 1]["grid"][None, :, :]).abs().amin(dim=(1, 2)) >= clearance
+    clear = torch.ones(x.size(0), dtype=torch.bool)
+    for s0 in range(0, x.size(0), 1 << 14):            # slabs: the [points, features, knots] differences are large
+        h = x[s0:s0 + (1 << 14)].double().to(device)
+        ok = torch.ones(h.size(0), dtype=torch.bool, device=device)
+        for li in range(len(layers) - 1):
+            h = O.layer_forward(h, layers[li], act)
+            ok &= (h[:, :, None] - layers[li + 1]["grid"][None, :, :]).abs().amin(dim=(1, 2)) >= clearance
+        clear[s0:s0 + (1 << 14)] = ok.cpu()
     x = x[clear]
     assert x.size(0) >= n
     return x[:n].contiguous()
@@ -381,6 +386,42 @@ def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
     step32(x.cuda())
     monkeypatch.delenv("PDEKAN_DISABLE_BF16X3")
     assert max_rel(g_split.cpu(), step32.flat_grad.cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("widths,G,N,shard", [([2, 64, 64, 1], 10, 1 << 20, 1 << 15),
+                                              ([2, 256, 256, 256, 1], 20, 1 << 17, 1 << 12)])
+def test_large_batch_gradients_match_fp64_oracle(widths, G, N, shard):
+    """The benchmark configuration at its full size (2^20 points) and the wide grid-20 model at 2^17: loss and every
+    parameter gradient of the fused step against the fp64 oracle, which is evaluated here on the GPU shard by shard
+    (the loss is a sum over points, pinn_step's n_global).  Long sums are where accumulation order and rounding
+    show: the matrix instructions' accumulate drifts with the length of a run of steps, which the weight-gradient
+    kernels bound (chunks of points, periodic vector adds)."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, G, 77)
+    # (a hidden value within fp32 rounding of a knot moves the gradients of the layers below by that point's whole
+    # contribution: such points are dropped, see _points_clear_of_knots)
+    x = _points_clear_of_knots(m, N, "silu", 1234, device="cuda")
+    layers64 = [{k: (v.double().cuda() if v is not None else None) for k, v in lay.items()}
+                for lay in O.layers_from_state_dict(m.state_dict())]
+    keys = ("base_weight", "spline_weight", "spline_scaler")
+    loss64, flat64 = 0.0, None
+    for s0 in range(0, N, shard):
+        r = O.pinn_step(x[s0:s0 + shard].double().cuda(), layers64, "silu", n_global=N)
+        loss64 += r["loss"].item()
+        flat = torch.cat([r["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in keys])
+        flat64 = flat if flat64 is None else flat64 + flat
+        del r
+    mg = m.cuda()
+    step = BlackScholesStep(mg)
+    loss = step(x.cuda()).item()
+    assert abs(loss - loss64) <= TOL * abs(loss64)
+    off = 0
+    for l, lay in enumerate(mg.layers):
+        for k in keys:
+            n = getattr(lay, k).numel()
+            err = max_rel(step.flat_grad[off:off + n].double(), flat64[off:off + n])
+            assert err <= TOL, (l, k, err)
+            off += n
 
 
 @pytest.mark.parametrize("sparse", ["1", "0"])
