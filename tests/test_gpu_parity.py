@@ -389,9 +389,11 @@ def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
 
 
 @pytest.mark.parametrize("widths,G,N,shard", [([2, 64, 64, 1], 10, 1 << 20, 1 << 15),
-                                              ([2, 256, 256, 256, 1], 20, 1 << 17, 1 << 12)])
+                                              ([2, 256, 256, 256, 1], 20, 1 << 17, 1 << 12),
+                                              ([6, 128, 128, 1], 10, 1 << 17, 1 << 12)])
 def test_large_batch_gradients_match_fp64_oracle(widths, G, N, shard):
-    """The benchmark configuration at its full size (2^20 points) and the wide grid-20 model at 2^17: loss and every
+    """The benchmark configuration at its full size (2^20 points), the wide grid-20 model and the 5-asset basket
+    model (12 jets per value, streaming kernels) at 2^17: loss and every
     parameter gradient of the fused step against the fp64 oracle, which is evaluated here on the GPU shard by shard
     (the loss is a sum over points, pinn_step's n_global).  Long sums are where accumulation order and rounding
     show: the matrix instructions' accumulate drifts with the length of a run of steps, which the weight-gradient
