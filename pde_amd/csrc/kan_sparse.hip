@@ -499,7 +499,11 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
 // ==========================================================================
 // Window tables (one aligned 16-byte LDS read per output) need G + 6 <= 16 slots and 64 or 128 outputs; every other
 // layer up to G = 20 and 256 outputs takes the raw-row tables (64 outputs per block, two ds_read2_b32 per output).
-static bool window_layout(const LayerView& L) { return L.G + 6 <= kSlots && (L.O == 64 || L.O == 128); }
+static bool window_layout(const LayerView& L) {
+  const char* raw = getenv("PDEKAN_FORCE_RAW_ROWS");     // A/B switch: raw rows also where a window table would fit
+  if (raw && raw[0] == '1' && L.I >= 8 && L.I % kFS == 0) return false;
+  return L.G + 6 <= kSlots && (L.O == 64 || L.O == 128);
+}
 static bool raw_layout(const LayerView& L) {
   return !window_layout(L) && L.G + 10 <= kRawRow && L.O % 64 == 0 && L.O <= 256 && L.I >= 8 && L.I % kFS == 0;
 }
