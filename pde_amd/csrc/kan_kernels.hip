@@ -477,6 +477,27 @@ __global__ void loss_finish_kernel(const float* __restrict__ loss_part, int npar
 // --------------------------------------------------------------------------
 static inline int pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
 
+// --------------------------------------------------------------------------
+// One 4-jet view of a 12-jet tensor (6 directions, 5 second derivatives): the
+// layer map is linear in the jets above the value, so a weight gradient over
+// (value, 6 firsts, 5 seconds) is the sum of 5 weight gradients over
+// (value, first k, [first 5 = time in pass 0], second k), k = 0..4, when the
+// cotangent's value jet is taken in pass 0 only.  in[e][12] -> out[e][4].
+// --------------------------------------------------------------------------
+__global__ void gather_jets4_kernel(const float* __restrict__ in, float4* __restrict__ out, int64_t total, int k,
+                                    int keep_value) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const float* src = in + e * 12;
+    out[e] = make_float4(keep_value ? src[0] : 0.0f, src[1 + k], k == 0 ? src[6] : 0.0f, src[7 + k]);
+  }
+}
+
+void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st) {
+  int64_t blocks = (elems + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  gather_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(in12, reinterpret_cast<float4*>(out4), elems, k, keep_value ? 1 : 0);
+}
+
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st) {
   grid_info_kernel<<<(L.I + 63) / 64, 64, 0, st>>>(L.grid, ginfo, L.I, L.nk());
 }

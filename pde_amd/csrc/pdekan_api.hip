@@ -159,12 +159,43 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
   return check_launch("layer backward");
 }
 
+// Weight gradients of a 12-jet layer (6 directions, 5 second derivatives) as 5 passes of the 4-jet matrix kernels
+// over gathered views (see gather_jets4_kernel): for layers those kernels take, in the fused step.
+bool split_weight_eligible(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  return D == 6 && D2 == 5 && n >= 16 && (L.G == 10 || L.G == 20) && pdekan::mfma_eligible(2, 1, L) &&
+         !getenv_flag("PDEKAN_DISABLE_JET_SPLIT");
+}
+constexpr int kSplitPasses = 5;
+
+// the split passes: 5 launches of the 4-jet weight-gradient kernels into consecutive groups of chunks, one reduction
+int run_weight_split(const pdekan::LayerView& L, const float* a, const float* gy, float* const* view, float* part,
+                     const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st, int li) {
+  if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
+    return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
+  const int nch = pdekan::mfma_weight_chunks(n, L);
+  const bool bf = pdekan::bf16x3_weight_eligible(2, 1, L, n);
+  {
+    ProfScope ps(st, bf ? "L%d.bwd_weight.mfma_bf16x3" : "L%d.bwd_weight.mfma", li);   // gathers included
+    for (int k = 0; k < kSplitPasses; ++k) {
+      pdekan::launch_gather_jets4(a, view[0], n * L.I, k, true, st);
+      pdekan::launch_gather_jets4(gy, view[1], n * L.O, k, k == 0, st);
+      pdekan::launch_bwd_weight_mfma(L, view[0], view[1], part + (size_t)k * nch * L.packed_floats(), nch, n, st, bf);
+    }
+  }
+  ProfScope ps(st, "L%d.reduce_unpack", li);
+  const int total = kSplitPasses * nch;
+  pdekan::launch_reduce_unpack(L, part, total, part + (size_t)total * L.packed_floats(), g->base_weight,
+                               g->spline_weight, L.scaler ? g->spline_scaler : nullptr, accumulate, st);
+  return check_launch("layer weight gradients (split passes)");
+}
+
 struct ModelPlan {
   std::vector<pdekan::LayerView> L;
   int D, D2, J;
   int64_t mb;           // points per micro-batch
   int maxw;             // widest activation
   size_t part_floats;   // largest partial buffer
+  size_t view_floats;   // one gathered 4-jet view of the widest activation, when some layer takes the split passes
 };
 
 int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2, int64_t micro_batch, ModelPlan& P) {
@@ -174,16 +205,22 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
   P.L.resize(n_layers);
   P.D = D; P.D2 = D2; P.J = 1 + D + D2;
   P.mb = (micro_batch <= 0 || micro_batch > n) ? n : micro_batch;
-  P.maxw = 0; P.part_floats = 0;
+  P.maxw = 0; P.part_floats = 0; P.view_floats = 0;
   for (int l = 0; l < n_layers; ++l) {
     int rc = to_view(&layers[l], P.L[l]);
     if (rc) return rc;
     if (l > 0 && P.L[l].I != P.L[l - 1].O) return fail(PDEKAN_ERR_ARG, "layer %d input width mismatch", l);
     if (P.L[l].I > P.maxw) P.maxw = P.L[l].I;
     if (P.L[l].O > P.maxw) P.maxw = P.L[l].O;
-    const size_t pf = (size_t)(weight_chunks(D, D2, P.L[l], P.mb) + 1) * P.L[l].packed_floats();
+    size_t pf = (size_t)(weight_chunks(D, D2, P.L[l], P.mb) + 1) * P.L[l].packed_floats();
+    if (split_weight_eligible(D, D2, P.L[l], P.mb)) {
+      const size_t ps = (size_t)(kSplitPasses * pdekan::mfma_weight_chunks(P.mb, P.L[l]) + 1) * P.L[l].packed_floats();
+      if (ps > pf) pf = ps;                  // a last micro-batch under 16 points takes the streaming kernel
+      P.view_floats = 1;
+    }
     if (pf > P.part_floats) P.part_floats = pf;
   }
+  if (P.view_floats) P.view_floats = (size_t)P.mb * P.maxw * 4;
   {
     const pdekan::LayerView& H = P.L.back();
     if (pdekan::head_eligible(D, H)) {
@@ -197,6 +234,7 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
 struct ModelWs {
   std::vector<float*> wp, wt, win, ginfo, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
   float* g[2];
+  float* view[2];       // gathered 4-jet views of a layer's input jets and cotangents (split passes), else nullptr
   float* part;
   float* loss_part;
 };
@@ -226,6 +264,8 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
   }
   W.g[0] = take((size_t)P.mb * P.maxw * P.J);
   W.g[1] = take((size_t)P.mb * P.maxw * P.J);
+  W.view[0] = P.view_floats ? take(P.view_floats) : nullptr;
+  W.view[1] = P.view_floats ? take(P.view_floats) : nullptr;
   W.part = take(P.part_floats);
   W.loss_part = take(kLossBlocks);
   if (need) *need = total;
@@ -422,8 +462,15 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     if (grads) {
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
-        rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, &grads[l], acc_flag,
-                          m, st, l);
+        if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
+          rc = run_weight_split(P.L[l], W.act[l], W.g[cur], W.view, W.part, &grads[l], acc_flag, m, st, l);
+          if (!rc && gnext)
+            rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, nullptr, acc_flag,
+                              m, st, l);
+        } else {
+          rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, &grads[l], acc_flag,
+                            m, st, l);
+        }
         if (rc) return rc;
         cur ^= 1;
       }

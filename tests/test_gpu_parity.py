@@ -441,6 +441,25 @@ def test_raw_row_sparse_layers_match_oracle(widths, G, N, sparse, monkeypatch):
     _grads_vs_oracle(m, x, "silu", widths)
 
 
+@pytest.mark.parametrize("widths,G,N", [([6, 64, 64, 1], 10, 1000), ([6, 32, 128, 64, 1], 20, 2064),
+                                        ([6, 64, 64, 1], 10, 16)])
+def test_basket_weight_gradients_in_five_four_jet_passes(widths, G, N, monkeypatch):
+    """6 inputs (5 assets + time): 12 jets per value.  The hidden layers' weight gradients are taken as 5 passes of
+    the 4-jet matrix kernels over gathered views (value, first k, time in pass 0, second k), the cotangent's value jet
+    in pass 0 only: against the fp64 oracle, and against the streaming 12-jet kernel on the same inputs."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, G, 500 + N)
+    x = _points_clear_of_knots(m, N, "silu", 21)
+    step = _grads_vs_oracle(m, x, "silu", widths)
+    g_split = step.flat_grad.clone()
+    monkeypatch.setenv("PDEKAN_DISABLE_JET_SPLIT", "1")
+    step1 = BlackScholesStep(m.cuda())
+    step1(x.cuda())
+    monkeypatch.delenv("PDEKAN_DISABLE_JET_SPLIT")
+    assert max_rel(g_split.cpu(), step1.flat_grad.cpu()) <= 3e-6
+    assert not torch.equal(g_split, step1.flat_grad)        # the switch selected something
+
+
 def test_split_bf16_and_fp32_blocks_share_one_layer():
     """A 96-input layer with three kinds of knot rows: features 0..31 equally spaced (split-bf16 kernel, polynomial
     pieces), 32..63 with a knot moved by h/100 (split-bf16 kernel, general triangle around the quotient guess),
