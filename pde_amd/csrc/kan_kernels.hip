@@ -492,6 +492,25 @@ __global__ void gather_jets4_kernel(const float* __restrict__ in, float4* __rest
   }
 }
 
+// the way back for input gradients: pass k of the 4-jet kernel gives (its share of d/d value, d/d first k,
+// d/d time in pass 0, d/d second k); the value shares add up over the passes.  in4[e] -> out12[e][12].
+__global__ void scatter_jets4_kernel(const float4* __restrict__ in, float* __restrict__ out, int64_t total, int k) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = in[e];
+    float* dst = out + e * 12;
+    dst[0] = (k == 0) ? v.x : dst[0] + v.x;
+    dst[1 + k] = v.y;
+    if (k == 0) dst[6] = v.z;
+    dst[7 + k] = v.w;
+  }
+}
+
+void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st) {
+  int64_t blocks = (elems + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  scatter_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(in4), out12, elems, k);
+}
+
 void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st) {
   int64_t blocks = (elems + 255) / 256;
   if (blocks > 65536) blocks = 65536;

@@ -24,6 +24,8 @@ struct LayerView {
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st);
 // out4[e] = (value or 0, first k, first 5 in pass 0 else 0, second k) of in12[e], e < elems, k = 0..4
 void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st);
+// out12[e] <- pass k's (value share, first k, time in pass 0, second k); the value shares are summed over k = 0..4
+void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st);
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st);
 bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
                       int I, hipStream_t st);

@@ -17,14 +17,16 @@
 // the data.  The table of feature i+1 is staged (global -> registers -> LDS,
 // double-buffered) while feature i is being consumed.
 //
+// A block takes 64 of a layer's outputs.  Wider layers go 64 at a time: the
+// forward grid has one block row per 64 outputs, the input-gradient kernel
+// walks the outputs 64 at a time and adds each pass into the gradients it
+// stored in the pass before (template parameter MG).
+//
 // Layers the window tables do not fit (more than 16 knot intervals: grid 20; 192
 // or 256 outputs) keep the weights as raw rows [output][3 zeros, C weights,
 // zeros] (32 floats): the 4 live weights are floats s .. s+3 of the row, read
 // at 4-byte alignment (two ds_read2_b32: half the LDS rate of the aligned
-// read, a quarter of the table size).  A block then takes 64 of the layer's
-// outputs: the forward grid has one block row per 64 outputs, the
-// input-gradient kernel walks the outputs 64 at a time and adds each pass
-// into the gradients it stored in the pass before.
+// read, a quarter of the table size).
 //
 //   forward:      y[p][o][:]     += sum_m w[o][i][s-3+m] * E_m[:] + w_b[o][i] * E_b[:]
 //   input grads:  G_m[:]          = sum_o w[o][i][s-3+m] * gy[p][o][:]   (+ base), then the
@@ -207,7 +209,8 @@ __device__ __forceinline__ void jets_stage(float* sJ, const float* a, const Wave
 // ==========================================================================
 // forward
 // ==========================================================================
-template <int O, int FS, int RS = 64>
+// MG (several groups of O outputs per layer): blockIdx.y picks the block's O of the layer's OTr outputs
+template <int O, int FS, int RS = 64, bool MG = (RS != 64)>
 __global__ void __launch_bounds__(256, 2)
 fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                   const float* __restrict__ win,
@@ -215,8 +218,8 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
   constexpr int OG = O / 32;              // output groups = lanes per point
   constexpr int PW = 64 / OG;             // points per wave
   constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
-  const int OT = (RS == 64) ? O : OTr;    // raw rows: blockIdx.y picks the block's O of the layer's OT outputs
-  const int o0 = (RS == 64) ? 0 : (int)blockIdx.y * O;
+  const int OT = MG ? OTr : O;
+  const int o0 = MG ? (int)blockIdx.y * O : 0;
   const int nk = G + 7;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);            // [2][O*RS]
@@ -336,7 +339,7 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
 // ==========================================================================
 // input-jet gradients
 // ==========================================================================
-template <int O, int RS = 64>
+template <int O, int RS = 64, bool MG = (RS != 64)>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
                         const float* __restrict__ ginfo, const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
@@ -344,9 +347,9 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   constexpr int OG = O / 32;
   constexpr int PW = 64 / OG;
   constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
-  // raw rows: the layer's OT outputs are walked O at a time, each pass adding its share to the input gradients
-  const int OT = (RS == 64) ? O : OTr;
-  const int npass = (RS == 64) ? 1 : OTr / O;
+  // MG: the layer's OT outputs are walked O at a time, each pass adding its share to the input gradients
+  const int OT = MG ? OTr : O;
+  const int npass = MG ? OTr / O : 1;
   const int nk = G + 7;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);
@@ -372,7 +375,7 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       f32x4 v = *reinterpret_cast<const f32x4*>(sOw + (lane + 64 * k) * 4);
       if ((lane + 64 * k) / kFS < wr.nlive) {
         // a later pass adds to what this same lane stored at this address in the pass before
-        if (RS != 64 && add) v += *reinterpret_cast<const f32x4*>(dst + wr.off[k]);
+        if (MG && add) v += *reinterpret_cast<const f32x4*>(dst + wr.off[k]);
         *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
       }
     }
@@ -555,14 +558,14 @@ static void big_lds(Kern k, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int O, int FS, int RS = 64>
+template <int O, int FS, int RS = 64, bool MG = (RS != 64)>
 static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));               // points per block
-  auto k = fwd_sparse_kernel<O, FS, RS>;
+  auto k = fwd_sparse_kernel<O, FS, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, false, FS);
   big_lds(k, lds);
-  const dim3 g((unsigned)((N + pts - 1) / pts), RS == 64 ? 1 : L.O / O);
+  const dim3 g((unsigned)((N + pts - 1) / pts), MG ? L.O / O : 1);
   k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O);
 }
 
@@ -572,17 +575,17 @@ void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, flo
   } else if (L.O == 64) {
     if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st);
     else fwd_sparse_launch<64, 2>(L, a, win, y, N, st);
-  } else {
-    fwd_sparse_launch<128, 4>(L, a, win, y, N, st);
+  } else {                                               // 128 outputs: two groups of 64 (faster than one lane group of 4 x 32)
+    fwd_sparse_launch<64, 4, 64, true>(L, a, win, y, N, st);
   }
 }
 
-template <int O, int RS = 64>
+template <int O, int RS = 64, bool MG = (RS != 64)>
 static void bwd_input_sparse_launch(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
                                     int64_t N, hipStream_t st) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));
-  auto k = bwd_input_sparse_kernel<O, RS>;
+  auto k = bwd_input_sparse_kernel<O, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, true);
   big_lds(k, lds);
   k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O);
@@ -592,7 +595,7 @@ void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy
                              int64_t N, hipStream_t st) {
   if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st);
   else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st);
-  else bwd_input_sparse_launch<128>(L, a, gy, win, ga, N, st);
+  else bwd_input_sparse_launch<64, 64, true>(L, a, gy, win, ga, N, st);
 }
 
 }  // namespace pdekan

@@ -91,7 +91,13 @@ int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }
 
+bool getenv_flag(const char* name);
+
+// 12-jet layers (6 directions, 5 second derivatives) whose gradients are taken in 5 passes of the 4-jet kernels
+bool split_jets(int D, int D2) { return D == 6 && D2 == 5 && !getenv_flag("PDEKAN_DISABLE_JET_SPLIT"); }
+
 size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
+  if (split_jets(D, D2) && pdekan::sparse_input_grad_eligible(2, 1, L)) return pdekan::sparse_table_floats(L);
   return pdekan::sparse_eligible(D, D2, L) ? pdekan::sparse_table_floats(L) : 0;
 }
 
@@ -162,31 +168,47 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
 // Weight gradients of a 12-jet layer (6 directions, 5 second derivatives) as 5 passes of the 4-jet matrix kernels
 // over gathered views (see gather_jets4_kernel): for layers those kernels take, in the fused step.
 bool split_weight_eligible(int D, int D2, const pdekan::LayerView& L, int64_t n) {
-  return D == 6 && D2 == 5 && n >= 16 && (L.G == 10 || L.G == 20) && pdekan::mfma_eligible(2, 1, L) &&
-         !getenv_flag("PDEKAN_DISABLE_JET_SPLIT");
+  return split_jets(D, D2) && n >= 16 && (L.G == 10 || L.G == 20) && pdekan::mfma_eligible(2, 1, L);
 }
 constexpr int kSplitPasses = 5;
 
-// the split passes: 5 launches of the 4-jet weight-gradient kernels into consecutive groups of chunks, one reduction
-int run_weight_split(const pdekan::LayerView& L, const float* a, const float* gy, float* const* view, float* part,
-                     const PdekanLayerGrad* g, int accumulate, int64_t n, hipStream_t st, int li) {
+// The split passes of one layer: per pass one gather of the input jets and of the cotangents, the 4-jet
+// weight-gradient kernels into consecutive groups of chunks (one reduction at the end) and, where the sparse
+// input-gradient kernel takes the layer, its 4-jet input gradients scattered back into the 12-jet tensor.
+// Returns through *ga_done whether the input gradients were produced here.
+int run_backward_split(const pdekan::LayerView& L, const float* a, const float* gy, const float* win, float* ga,
+                       float* const* view, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
+                       hipStream_t st, int li, bool* ga_done) {
   if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
     return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
   const int nch = pdekan::mfma_weight_chunks(n, L);
   const bool bf = pdekan::bf16x3_weight_eligible(2, 1, L, n);
-  {
-    ProfScope ps(st, bf ? "L%d.bwd_weight.mfma_bf16x3" : "L%d.bwd_weight.mfma", li);   // gathers included
-    for (int k = 0; k < kSplitPasses; ++k) {
+  const bool with_ga = ga && win && pdekan::sparse_input_grad_eligible(2, 1, L);
+  for (int k = 0; k < kSplitPasses; ++k) {
+    {
+      ProfScope ps(st, "L%d.gather_views", li);
       pdekan::launch_gather_jets4(a, view[0], n * L.I, k, true, st);
       pdekan::launch_gather_jets4(gy, view[1], n * L.O, k, k == 0, st);
+    }
+    {
+      ProfScope ps(st, bf ? "L%d.bwd_weight.mfma_bf16x3" : "L%d.bwd_weight.mfma", li);
       pdekan::launch_bwd_weight_mfma(L, view[0], view[1], part + (size_t)k * nch * L.packed_floats(), nch, n, st, bf);
     }
+    if (with_ga) {
+      {
+        ProfScope ps(st, "L%d.bwd_input.sparse", li);
+        pdekan::launch_bwd_input_sparse(L, view[0], view[1], win, view[2], n, st);
+      }
+      ProfScope ps(st, "L%d.scatter_views", li);
+      pdekan::launch_scatter_jets4(view[2], ga, n * L.I, k, st);
+    }
   }
+  *ga_done = with_ga;
   ProfScope ps(st, "L%d.reduce_unpack", li);
   const int total = kSplitPasses * nch;
   pdekan::launch_reduce_unpack(L, part, total, part + (size_t)total * L.packed_floats(), g->base_weight,
                                g->spline_weight, L.scaler ? g->spline_scaler : nullptr, accumulate, st);
-  return check_launch("layer weight gradients (split passes)");
+  return check_launch("layer backward (split passes)");
 }
 
 struct ModelPlan {
@@ -234,7 +256,7 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
 struct ModelWs {
   std::vector<float*> wp, wt, win, ginfo, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
   float* g[2];
-  float* view[2];       // gathered 4-jet views of a layer's input jets and cotangents (split passes), else nullptr
+  float* view[3];       // 4-jet views of a layer's input jets, cotangents and input gradients (split passes), else nullptr
   float* part;
   float* loss_part;
 };
@@ -266,6 +288,7 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
   W.g[1] = take((size_t)P.mb * P.maxw * P.J);
   W.view[0] = P.view_floats ? take(P.view_floats) : nullptr;
   W.view[1] = P.view_floats ? take(P.view_floats) : nullptr;
+  W.view[2] = P.view_floats ? take(P.view_floats) : nullptr;
   W.part = take(P.part_floats);
   W.loss_part = take(kLossBlocks);
   if (need) *need = total;
@@ -463,8 +486,10 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
         if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
-          rc = run_weight_split(P.L[l], W.act[l], W.g[cur], W.view, W.part, &grads[l], acc_flag, m, st, l);
-          if (!rc && gnext)
+          bool ga_done = false;
+          rc = run_backward_split(P.L[l], W.act[l], W.g[cur], W.win[l], gnext, W.view, W.part, &grads[l], acc_flag, m, st,
+                                  l, &ga_done);
+          if (!rc && gnext && !ga_done)
             rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, nullptr, acc_flag,
                               m, st, l);
         } else {
