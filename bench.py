@@ -73,7 +73,7 @@ def kernel_cost(name, widths, grid, n_pts, J):
 
 
 HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
-                 "fwd.sparse": "fwd_sparse_kernel<64, 4>", "head_fused": "head_bs_kernel<"}
+                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "head_fused": "head_bs_kernel<"}
 
 
 def profiled_traffic(kname, name, n_local):
