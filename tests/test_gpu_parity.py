@@ -458,6 +458,11 @@ def test_basket_weight_gradients_in_five_four_jet_passes(widths, G, N, monkeypat
     monkeypatch.delenv("PDEKAN_DISABLE_JET_SPLIT")
     assert max_rel(g_split.cpu(), step1.flat_grad.cpu()) <= 3e-6
     assert not torch.equal(g_split, step1.flat_grad)        # the switch selected something
+    if N > 400:                                              # micro-batches: the passes accumulate across them
+        mb = BlackScholesStep(m.cuda(), micro_batch=400)
+        loss_mb = mb(x.cuda()).item()
+        assert abs(loss_mb - step.loss.item()) <= 1e-6 * abs(loss_mb)
+        assert max_rel(mb.flat_grad.cpu(), g_split.cpu()) <= 3e-6
 
 
 def test_split_bf16_and_fp32_blocks_share_one_layer():
