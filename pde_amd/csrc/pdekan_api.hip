@@ -91,8 +91,6 @@ int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }
 
-bool getenv_flag(const char* name);
-
 // 12-jet layers (6 directions, 5 second derivatives) whose gradients are taken in 5 passes of the 4-jet kernels
 bool split_jets(int D, int D2) { return D == 6 && D2 == 5 && !getenv_flag("PDEKAN_DISABLE_JET_SPLIT"); }
 
