@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark: collocation points per second of one KAN-PINN train step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--graph]
 
 One step = forward with analytic input derivatives + Black-Scholes residual +
 mean-squared loss + backward to every parameter gradient (one call into
@@ -9,14 +9,17 @@ libpdekan.so), + gradient all-reduce over RCCL when N > 1, + an AdamW update.
 Points and weights are synthetic (seeded), resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-Workloads:
-  cfg1  KAN [2,5,1]            grid 5   10^4 points
-  cfg2  KAN [2,64,64,1]        grid 10  2^20 points per GPU   (default at --gpus 1)
-  cfg3  = cfg2 sharded, 2^24 points over 8 GPUs -> 2^21 per GPU (default at --gpus > 1)
-  cfg4  KAN [2,256,256,256,1]  grid 20  2^22 points in total
-  cfg5  KAN [6,128,128,1]      grid 10  2^22 points in total, 5 assets + time
+Workloads (the global point set is drawn once from seed 0 whatever the rank count; rank r takes the r-th
+contiguous shard, so a strong-scaling workload sees the same points at every N):
+  cfg1  KAN [2,5,1]            grid 5   10^4 points per GPU            (weak)
+  cfg2  KAN [2,64,64,1]        grid 10  2^20 points per GPU            (weak; default at --gpus 1)
+  cfg3  = cfg2 at 2^21 points per GPU: 2^24 over 8 GPUs                (weak; default at --gpus > 1)
+  cfg4  KAN [2,256,256,256,1]  grid 20  2^22 points in total           (strong)
+  cfg5  KAN [6,128,128,1]      grid 10  2^22 points in total, 5 assets + time (strong)
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -28,10 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # dense fp32 matrix peak of MI355X (= fp32 vector peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 matrix peak
-BF16X3_PRODUCTS = 6               # bf16 products per fp32-accurate product in the split-bf16 weight-gradient kernel
+PEAK_FP32_TFLOPS = 157.3          # dense fp32 matrix peak of MI355X (= fp32 vector peak)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+# 16-bit MFMA products per fp32-accurate product in the split-operand kernels
+SPLIT_PRODUCTS = {"mfma_bf16x3": 6, "mfma_f16x2": 3}
 
 WORKLOADS = {
     "cfg1": dict(widths=[2, 5, 1], grid=5, pts_per_gpu=10_000),
@@ -44,20 +48,28 @@ CPU_SAMPLE = {"cfg1": 10_000, "cfg2": 1 << 14, "cfg3": 1 << 14, "cfg4": 1 << 10,
 
 
 def kernel_cost(name, widths, grid, n_pts, J):
-    """Algorithmic work of one launch of kernel `name` on n_pts points:
-    (flops, bytes).  flops: the dense contraction 2*J*I*(C+1)*O per point;
-    bytes: jets read and written, fp32, each tensor once."""
+    """Algorithmic work of one launch of kernel `name` on n_pts points.
+
+    Returns (dense_flops, formulation_flops, peak_tflops, bytes):
+      dense_flops        2*J*I*(C+1)*O per point and contraction (every column of the expanded basis)
+      formulation_flops  what the kernel's formulation has to execute: the dense count for the matrix-core
+                         kernels, the 4 live spline columns + the base column (5 of C+1) for the kernels that
+                         gather live weights on the vector ALUs (sparse, streaming, fused head)
+      peak_tflops        peak of the unit that formulation runs on (fp32 vector = fp32 matrix = 157.3; the
+                         split-operand kernels: 16-bit matrix peak / products per fp32 product)
+      bytes              jets read and written, fp32, each tensor once."""
     C1 = grid + 4
     if not name.startswith("L"):
         if name == "bs_residual_loss":
-            return 0.0, n_pts * 4.0 * (2 * J + widths[0])
+            return 0.0, 0.0, PEAK_FP32_TFLOPS, n_pts * 4.0 * (2 * J + widths[0])
         if name == "seed_jets":
-            return 0.0, n_pts * 4.0 * widths[0] * (1 + J)
-        return 0.0, 0.0
+            return 0.0, 0.0, PEAK_FP32_TFLOPS, n_pts * 4.0 * widths[0] * (1 + J)
+        return 0.0, 0.0, PEAK_FP32_TFLOPS, 0.0
     layer = int(name[1:name.index(".")])
     I, O = widths[layer], widths[layer + 1]
-    kind = name.split(".")[1]
-    flops = 2.0 * J * I * C1 * O * n_pts
+    parts = name.split(".")
+    kind, impl = parts[1], (parts[2] if len(parts) > 2 else "")
+    dense = 2.0 * J * I * C1 * O * n_pts
     if kind == "fwd":
         byts = 4.0 * J * (I + O) * n_pts
     elif kind == "bwd_input":
@@ -65,43 +77,84 @@ def kernel_cost(name, widths, grid, n_pts, J):
     elif kind == "bwd_weight":
         byts = 4.0 * J * (I + O) * n_pts
     elif kind == "head_fused":              # last layer fwd + residual + loss + its bwd in one pass
-        flops = 3.0 * flops
+        dense = 3.0 * dense
         byts = 4.0 * (J * 2 * I + widths[0]) * n_pts
+        impl = "stream"
+    elif kind in ("gather_views", "scatter_views"):   # 12-jet tensor <-> 4-jet view of the widest side
+        return 0.0, 0.0, PEAK_FP32_TFLOPS, 4.0 * (12 + 4) * max(I, O) * n_pts
     else:                                   # reduce_unpack: O(parameters)
-        return 0.0, 0.0
-    return flops, byts
+        return 0.0, 0.0, PEAK_FP32_TFLOPS, 0.0
+    if impl in SPLIT_PRODUCTS:
+        return dense, dense, PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[impl], byts
+    if impl in ("mfma", "mfma_skinny"):
+        return dense, dense, PEAK_FP32_TFLOPS, byts
+    return dense, dense * 5.0 / C1, PEAK_FP32_TFLOPS, byts
 
 
-HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
-                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "head_fused": "head_bs_kernel<"}
+def roofline_seconds(cost):
+    """Lower bound of one launch and which roof gives it."""
+    _, form, peak, byts = cost
+    t_f, t_b = form / (peak * 1e12), byts / (PEAK_HBM_GBS * 1e9)
+    return (t_f, "mfma") if t_f >= t_b else (t_b, "hbm")
+
+
+HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<",
+                 "bwd_weight.mfma_f16x2": "bwd_weight_f16x2_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
+                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": "fwd_f16x2_kernel<",
+                 "bwd_input.mfma_f16x2": "bwd_input_f16x2_kernel<", "head_fused": "head_bs_kernel<"}
+
+
+def sources_digest():
+    """sha256 over the kernel sources: ties a committed counter summary to the code it was measured on."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "pde_amd", "csrc", "*"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def profiled_traffic(kname, name, n_local):
-    """HBM bytes per launch of kernel `kname` from the committed rocprofv3 PMC summary
-    (2 x FETCH_SIZE + WRITE_SIZE, KB; FETCH_SIZE counts half the bytes of wide reads on gfx950).
-    The summary was taken on cfg2 at 2^20 points per GPU: only that workload gets a number."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.txt")
+    """HBM bytes per launch of kernel `kname` from a committed rocprofv3 PMC summary under profiles/
+    (2 x FETCH_SIZE + WRITE_SIZE, KB; FETCH_SIZE counts half the bytes of wide reads on gfx950).  A summary
+    only counts when its header names this workload, this per-GPU point count and the digest of the kernel
+    sources it was taken on; otherwise the live line must not quote it."""
     hip = HIP_KERNEL_OF.get(kname.split(".", 1)[1] if "." in kname else kname)
-    if name not in ("cfg2",) or n_local != (1 << 20) or hip is None or not os.path.exists(path):
-        return None
-    fetch = write = None
-    for line in open(path):
-        if line.startswith(hip.split("<")[0]) and hip in line:
-            for tok in line.split():
-                if tok.startswith("FETCH_SIZE="):
-                    fetch = float(tok.split("=")[1])
-                if tok.startswith("WRITE_SIZE="):
-                    write = float(tok.split("=")[1])
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+    if hip is None:
+        return None, None
+    want = f"# workload={name} n_local={n_local} sources={sources_digest()}"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.txt")), reverse=True):
+        with open(path) as f:
+            lines = f.read().splitlines()
+        if not lines or lines[0].strip() != want:
+            continue
+        fetch = write = None
+        for line in lines:
+            if line.startswith(hip.split("<")[0]) and hip in line:
+                for tok in line.split():
+                    if tok.startswith("FETCH_SIZE="):
+                        fetch = float(tok.split("=")[1])
+                    if tok.startswith("WRITE_SIZE="):
+                        write = float(tok.split("=")[1])
+        if fetch is not None and write is not None:
+            return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def host_threads():
+    """Host cores this process may use: its CPU affinity, capped by OMP_NUM_THREADS (a one-GPU box grants 16 of
+    the machine's cores and exports that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cap = os.environ.get("OMP_NUM_THREADS")
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
 
 
 def cpu_baseline(name, model_sd, widths, act, steps=2):
     """The reference algorithm (dense Cox-de Boor + F.linear + nested autograd)
     on the host cores, on a bounded sample of the same workload."""
     from oracle import kan_oracle as O
-    threads = min(16, os.cpu_count() or 1)
+    threads = host_threads()
     torch.set_num_threads(threads)
     n = CPU_SAMPLE[name]
     x = torch.rand(n, widths[0], generator=torch.Generator().manual_seed(0))
@@ -113,7 +166,20 @@ def cpu_baseline(name, model_sd, widths, act, steps=2):
     dt = (time.perf_counter() - t0) / steps
     return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
             "sample": f"{steps} steps of {n} points of the same model and point distribution, "
-                      f"{dt:.2f} s/step, PyTorch CPU fp32"}
+                      f"{dt:.2f} s/step, PyTorch CPU fp32, all {threads} host cores granted to this process"}
+
+
+def cpu_baseline_cfg1(act, steps=5):
+    """BASELINE.json's CPU-runnable configuration (KAN [2,5,1] grid 5, 10^4 points) on the host cores."""
+    from oracle import kan_oracle as O
+    from pde_amd import KAN
+    torch.manual_seed(0)
+    wl = WORKLOADS["cfg1"]
+    act_cls = torch.nn.SiLU if act == "silu" else torch.nn.Identity
+    m = KAN(wl["widths"], grid_size=wl["grid"], base_activation=act_cls)
+    base = cpu_baseline("cfg1", {k: v.detach().clone() for k, v in m.state_dict().items()}, wl["widths"], act, steps)
+    base["workload"] = "cfg1: KAN [2,5,1] grid=5, 10000 points"
+    return base
 
 
 def main():
@@ -125,8 +191,12 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
     ap.add_argument("--base-activation", default="silu", choices=["silu", "identity"],
                     help="silu = the module default (kan.py:18); identity = what the scripts pass (run1.py:478-482)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (library call + all-reduce + AdamW) in a HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip the AdamW update")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="skip the short extra run at cfg3's per-GPU point count on the default one-GPU line")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the all-reduce path")
     args = ap.parse_args()
@@ -161,37 +231,52 @@ def main():
             os.close(saved_fd)
 
     from pde_amd import KAN, _lib
-    from pde_amd.dist import DataParallelStep
+    from pde_amd.dist import DataParallelStep, shard_bounds
     from pde_amd.pinn import BlackScholesStep
 
+    default_line = args.workload is None
     name = args.workload or ("cfg2" if world == 1 else "cfg3")
     wl = WORKLOADS[name]
     widths, grid = wl["widths"], wl["grid"]
-    n_local = wl["pts_per_gpu"] if "pts_per_gpu" in wl else wl["pts_total"] // world
-    n_global = n_local * world
+    scaling = "weak" if "pts_per_gpu" in wl else "strong"
+    n_global = wl["pts_per_gpu"] * world if scaling == "weak" else wl["pts_total"]
     d = widths[0]
     J = 2 * d
 
-    torch.manual_seed(0)                                   # reference-compatible seeded init
+    torch.manual_seed(0)                                   # reference-compatible seeded init, the same on every rank
     act_cls = torch.nn.SiLU if args.base_activation == "silu" else torch.nn.Identity
     model = KAN(widths, grid_size=grid, base_activation=act_cls).to(dev)
-    # the same global point set whatever the rank count: rank r takes the r-th contiguous shard
-    gen = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(n_local, d, generator=gen).to(dev)
+    # ONE global point set from seed 0, whatever the rank count; rank r keeps the r-th contiguous shard
+    lo, hi = shard_bounds(n_global, rank, world)
+    x = torch.rand(n_global, d, generator=torch.Generator().manual_seed(0))[lo:hi].contiguous().to(dev)
+    n_local = hi - lo
 
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     step = BlackScholesStep(model, micro_batch=args.micro_batch)
-    dp = DataParallelStep(step, dist) if dist is not None else None
-    opt = torch.optim.AdamW(model.parameters(), lr=0.01, fused=True)   # run1.py:209; one launch for all tensors
+    dp = DataParallelStep(step, dist, sync="check") if dist is not None else None
+    # run1.py:209; one launch for all tensors; capturable keeps the step count on the device (graph replay)
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, fused=True, capturable=args.graph)
 
-    def one_step():
+    def eager_step():
         if dp is not None:
             loss = dp(x, n_global=n_global)
         else:
-            loss = step(x)
+            loss = step(x, n_global=n_global)
         if not args.no_optimizer:
             opt.step()
         return loss
+
+    loss_first = float(eager_step().item())                # also allocates the workspace and the optimiser state
+    one_step = eager_step
+    if args.graph:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager_step()
+
+        def one_step():
+            graph.replay()
+            return step.loss
 
     for _ in range(args.warmup):
         one_step()
@@ -225,72 +310,85 @@ def main():
     n_launch_pts = n_local if args.micro_batch <= 0 else min(args.micro_batch, n_local)
     kernels = {}
     for kname, (ms, cnt) in prof.items():
-        # 12-jet layers run the 4-jet matrix / sparse kernels in 5 passes over gathered views: 4 jets per launch
+        # 12-jet layers may run the 4-jet matrix / sparse kernels in 5 passes over gathered views: 4 jets per launch
         Jk = 4 if (J == 12 and (".mfma" in kname or kname.endswith(".sparse"))) else J
-        fl, by = kernel_cost(kname, widths, grid, n_launch_pts, Jk)
+        cost = kernel_cost(kname, widths, grid, n_launch_pts, Jk)
+        t_roof, bound = roofline_seconds(cost)
         kernels[kname] = {"avg_ms": ms / cnt, "launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
-                          "flops": fl, "bytes": by}
+                          "dense_flops": cost[0], "flops": cost[1], "peak": cost[2], "bytes": cost[3],
+                          "roof_ms": 1e3 * t_roof, "bound": bound}
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     kd = kernels[dom]
-    if dom.endswith(".mfma") or dom.endswith(".sparse"):
-        # dense contraction flops against the fp32 peak (matrix = vector peak on this chip).  The sparse-support
-        # kernels run on the vector ALUs and skip the 9 of 14 columns that are zero at a point: their dense-equivalent
-        # rate can exceed what the ALUs execute; frac is priced on the flops they execute (5/14 of dense).
-        live = (5.0 / (grid + 4)) if dom.endswith(".sparse") else 1.0
-        ach = live * kd["flops"] / (kd["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
-                "algorithmic_flops_per_launch": live * kd["flops"]}
-        if live < 1.0:
-            roof["note"] = "fp32 vector ALUs (packed FMA), flops of the live columns only"
-            roof["dense_equivalent_tflops"] = kd["flops"] / (kd["avg_ms"] * 1e-3) / 1e12
-    elif dom.endswith(".mfma_bf16x3"):
-        # fp32-accurate products made of 6 bf16 products each: price the algorithmic fp32 flops against bf16 peak / 6
-        peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
+    if kd["bound"] == "mfma":
         ach = kd["flops"] / (kd["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None, "avg_launch_ms": kd["avg_ms"],
-                "algorithmic_flops_per_launch": kd["flops"],
-                "note": "split-bf16 (3 pieces per operand, 6 bf16 MFMA products per fp32 product): peak = 2500 / 6"}
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": kd["peak"], "unit": "TFLOP/s",
+                "frac": ach / kd["peak"], "traffic": None, "avg_launch_ms": kd["avg_ms"],
+                "algorithmic_flops_per_launch": kd["flops"], "algorithmic_bytes_per_launch": kd["bytes"]}
+        impl = dom.split(".")[2] if dom.count(".") >= 2 else ""
+        if impl in SPLIT_PRODUCTS:
+            roof["note"] = (f"fp32-accurate products out of {SPLIT_PRODUCTS[impl]} 16-bit matrix products each: dense "
+                            f"algorithmic flops against {PEAK_16BIT_MFMA_TFLOPS:.0f} / {SPLIT_PRODUCTS[impl]} TFLOP/s")
+        elif kd["flops"] < kd["dense_flops"]:
+            roof["note"] = "fp32 vector ALUs (packed FMA): flops of the 5 live columns per feature only, fp32 vector peak"
+            roof["dense_equivalent_tflops"] = kd["dense_flops"] / (kd["avg_ms"] * 1e-3) / 1e12
     else:
         ach = kd["bytes"] / (kd["avg_ms"] * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
                 "algorithmic_bytes_per_launch": kd["bytes"]}
-    roof["traffic"] = profiled_traffic(dom, name, n_local)
-    if roof["traffic"] is not None:
-        roof["traffic_source"] = "profiles/r01_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-        roof["algorithmic_bytes_per_launch"] = kd["bytes"]
-    step_flops = sum(k["flops"] * k["launches_per_step"] for k in kernels.values())
+    roof["traffic"], src = profiled_traffic(dom, name, n_local)
+    if src:
+        roof["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)"
+    step_dense = sum(k["dense_flops"] * k["launches_per_step"] for k in kernels.values())
     kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
-    def _roof_s(kname, k):
-        """Lower bound of one launch: the flops the kernel's formulation needs at its unit's peak, or its bytes."""
-        peak = (PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS) if kname.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
-        need = k["flops"] * ((5.0 / (grid + 4)) if kname.endswith(".sparse") else 1.0)
-        return max(need / (peak * 1e12), k["bytes"] / (PEAK_HBM_GBS * 1e9))
-    step_roof_ms = 1e3 * sum(k["launches_per_step"] * _roof_s(n_, k) for n_, k in kernels.items())
+    step_roof_ms = sum(k["launches_per_step"] * k["roof_ms"] for k in kernels.values())
 
     out = {
         "metric": "collocation pts/s per KAN-PINN train step",
         "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: KAN {widths} grid={grid} k=3 {'SiLU' if args.base_activation == 'silu' else 'Identity'}, Black-Scholes PINN step "
                                f"(fwd + residual + loss + bwd + AdamW), {n_local} points/GPU, {n_global} total",
                    "points_per_gpu": n_local, "points_total": n_global, "micro_batch": args.micro_batch,
-                   "optimizer_in_step": not args.no_optimizer, "parallelism": f"dp{world}"},
-        "loss": loss_val,
+                   "optimizer_in_step": not args.no_optimizer, "hip_graph": bool(args.graph),
+                   "parallelism": f"dp{world}", "ranks": world,
+                   "points": "global set from seed 0, contiguous shard per rank"},
+        "loss_first_step": loss_first, "loss": loss_val,
         "roofline": roof,
-        "step_dense_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+        "step_dense_tflops": step_dense / (ms_per_step * 1e-3) / 1e12,
         # whole-step roofline: sum over the kernels of max(flops of the formulation / its peak, algorithmic bytes / HBM peak)
         "step_roofline_ms": step_roof_ms,
         "step_roofline_frac": step_roof_ms / ms_per_step,
         "kernel_ms_per_step": kernel_ms,
-        "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
+        "workspace_bytes": int(step._ws.numel()) if step._ws is not None else None,
+        "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"],
+                        "bound": v["bound"], "roof_frac": round(v["roof_ms"] / v["avg_ms"], 4) if v["avg_ms"] > 0 else None}
                     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
     }
+    # The multi-GPU series runs cfg3 (2^21 points per GPU); the default one-GPU line is cfg2 (2^20).  So that the
+    # series has a one-GPU point with the same per-GPU work, the default line also times a few steps at 2^21.
+    if world == 1 and default_line and not args.no_scaling_reference and not args.graph:
+        n_ref = WORKLOADS["cfg3"]["pts_per_gpu"]
+        x_ref = torch.rand(n_ref, d, generator=torch.Generator().manual_seed(0)).to(dev)
+        for _ in range(3):
+            step(x_ref, n_global=n_ref)
+            opt.step()
+        torch.cuda.synchronize()
+        k_ref = max(5, args.steps // 5)
+        t0 = time.perf_counter()
+        for _ in range(k_ref):
+            step(x_ref, n_global=n_ref)
+            opt.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["weak_scaling_reference"] = {"workload": "cfg3 shard: 2^21 points on one GPU", "points_per_gpu": n_ref,
+                                         "steps": k_ref, "ms_per_step": 1e3 * dt / k_ref, "value": n_ref * k_ref / dt}
+        del x_ref
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(name, sd0, widths, args.base_activation)
+        if name != "cfg1":
+            out["cpu_baseline_cfg1"] = cpu_baseline_cfg1(args.base_activation)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

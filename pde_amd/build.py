@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdekan.so")
 SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "pdekan_api.hip"]
-HEADERS = ["kan_math.h", "kan_launch.h", os.path.join("..", "..", "include", "pdekan.h")]
+INCLUDE = os.path.join(HERE, "..", "include")
 ARCH = "gfx950"
 
 
@@ -32,7 +32,9 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    # every header next to the sources and every public header: a new one cannot be forgotten
+    headers = [os.path.join(d, f) for d in (CSRC, INCLUDE) for f in sorted(os.listdir(d)) if f.endswith(".h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + headers + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

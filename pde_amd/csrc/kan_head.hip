@@ -179,14 +179,24 @@ static int head_waves(const LayerView& L) {
   return 1;
 }
 
+// dynamic LDS of a block: knot rows (+ 1/h), the packed weights, one gradient table per wave, the waves' loss sums
+static size_t head_lds_bytes(const LayerView& L) {
+  const int nw = head_waves(L);
+  return ((size_t)L.I * (L.nk() + 1) + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
+}
+
+constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup
+
+// Wide heads on fine grids (256 inputs at grid 48 and up) do not fit the LDS: those take the unfused
+// last-layer kernels + bs_residual_kernel.
 bool head_eligible(int D, const LayerView& L) {
-  return (D == 2 || D == 6) && L.O == 1 && L.I <= 256;
+  return (D == 2 || D == 6) && L.O == 1 && L.I <= 256 && head_lds_bytes(L) <= kLdsPerBlockMax;
 }
 
 int head_blocks(int64_t N, const LayerView& L) {
   const int nw = head_waves(L);
   int64_t b = (N + (int64_t)nw * 16 - 1) / ((int64_t)nw * 16);
-  if (b > 1280) b = 1280;                                 // 5 blocks per CU: the register budget's limit
+  if (b > kHeadBlocksMax) b = kHeadBlocksMax;             // 5 blocks per CU: the register budget's limit
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -196,7 +206,7 @@ static void head_launch(const LayerView& L, const float* a, const float* x, int6
                         const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                         float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
   const int nw = head_waves(L);
-  const size_t lds = ((size_t)L.I * (L.nk() + 1) + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
+  const size_t lds = head_lds_bytes(L);
   auto k = head_bs_kernel<D, D2, NF>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

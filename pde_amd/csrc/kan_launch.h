@@ -46,6 +46,7 @@ void launch_loss_finish(const float* loss_part, int nparts, float inv_n, float* 
                         hipStream_t st);
 
 // kan_head.hip: last layer (one output) + residual + loss + its backward, fused
+constexpr int kHeadBlocksMax = 1280;     // most blocks head_blocks() returns: one loss partial and one gradient table each
 bool head_eligible(int D, const LayerView& L);
 int head_blocks(int64_t N, const LayerView& L);
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t stride_n, int64_t stride_d,

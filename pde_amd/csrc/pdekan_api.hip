@@ -259,7 +259,10 @@ struct ModelWs {
   float* loss_part;
 };
 
-constexpr int kLossBlocks = 1024;
+constexpr int kLossBlocks = 1024;        // blocks of bs_residual_kernel (unfused residual + loss)
+// one float per block of whichever kernel writes the loss partials
+constexpr int kLossPartials = kLossBlocks > pdekan::kHeadBlocksMax ? kLossBlocks : pdekan::kHeadBlocksMax;
+static_assert(kLossPartials >= pdekan::kHeadBlocksMax && kLossPartials >= kLossBlocks, "loss partials cover every block");
 
 bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* need) {
   Carver c(ws, ws ? ws_bytes : 0);
@@ -288,7 +291,7 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
   W.view[1] = P.view_floats ? take(P.view_floats) : nullptr;
   W.view[2] = P.view_floats ? take(P.view_floats) : nullptr;
   W.part = take(P.part_floats);
-  W.loss_part = take(kLossBlocks);
+  W.loss_part = take(kLossPartials);
   if (need) *need = total;
   return ws ? c.ok : true;
 }

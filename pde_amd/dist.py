@@ -29,6 +29,28 @@ def shard_points(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return x[lo:hi]
 
 
+def sync_replicas(tensors, dist_module, check_only: bool = False) -> None:
+    """Make the replicated tensors of every rank equal to rank 0's (one broadcast of one flat message), or, with
+    ``check_only``, compare them with rank 0's and raise ``RuntimeError`` on the ranks that differ."""
+    tensors = [t.detach() for t in tensors]
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    ref = flat.clone()
+    dist_module.broadcast(ref, src=0)
+    if check_only:
+        bad = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        if not torch.equal(ref, flat):
+            bad += 1
+        dist_module.all_reduce(bad, op=dist_module.ReduceOp.SUM)      # every rank learns of a mismatch anywhere
+        if bad.item() > 0:
+            raise RuntimeError(f"pde_amd.dist: replicated tensors differ from rank 0's on {int(bad.item())} rank(s); "
+                               "seed or load every rank identically, or pass sync='broadcast'")
+        return
+    off = 0
+    for t in tensors:
+        t.copy_(ref[off: off + t.numel()].view_as(t).to(t.dtype))
+        off += t.numel()
+
+
 class FlatAllReduce:
     """Sum ``flat_grad`` and ``loss`` over the ranks with a single collective."""
 
@@ -56,9 +78,20 @@ class DataParallelStep:
     """Wrap a fused step (``pde_amd.pinn.BlackScholesStep`` or anything with the
     same call signature and a ``flat_grad`` buffer) for N ranks."""
 
-    def __init__(self, step, dist_module):
+    def __init__(self, step, dist_module, params=None, sync: str = "broadcast"):
+        """``params``: the replicated tensors (parameters and knot buffers); default: the ``state_dict`` of
+        ``step.model`` when the step has one.  Replicas only stay identical if they start identical, so at
+        construction the tensors are made so: ``sync="broadcast"`` copies rank 0's values to every rank,
+        ``sync="check"`` raises when a rank differs from rank 0, ``sync="none"`` trusts the caller."""
         self.step = step
         self.reduce = FlatAllReduce(step.flat_grad, dist_module, getattr(step, "grad_and_loss", None))
+        if params is None:
+            model = getattr(step, "model", None)
+            params = list(model.state_dict().values()) if model is not None else []
+        if sync not in ("broadcast", "check", "none"):
+            raise ValueError(f"sync must be 'broadcast', 'check' or 'none', got {sync!r}")
+        if sync != "none" and params:
+            sync_replicas(params, dist_module, check_only=(sync == "check"))
 
     def __call__(self, x_shard: torch.Tensor, n_global: int, target: Optional[torch.Tensor] = None) -> torch.Tensor:
         loss = self.step(x_shard, target=target, n_global=n_global)

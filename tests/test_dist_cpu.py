@@ -54,6 +54,59 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
+def _layer_tensors(layers):
+    return [p[k] for p in layers for k in ("grid", "base_weight", "spline_weight", "spline_scaler")]
+
+
+def _worker_mismatched(rank, world, port, n_total, q):
+    """Ranks that initialise with different seeds: 'check' must raise on every rank, 'broadcast' must repair."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from oracle import kan_oracle as O
+    from pde_amd.dist import DataParallelStep, shard_points
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    layers = O.random_layers([2, 8, 1], 5, seed=3 + rank)
+    step = OracleStep(layers, "silu")
+    raised = False
+    try:
+        DataParallelStep(step, dist, params=_layer_tensors(layers), sync="check")
+    except RuntimeError:
+        raised = True
+    dp = DataParallelStep(step, dist, params=_layer_tensors(layers), sync="broadcast")
+    x = torch.rand(n_total, 2, generator=torch.Generator().manual_seed(4))
+    loss = dp(shard_points(x, rank, world), n_global=n_total)
+    q.put((rank, raised, float(loss), dp.step.flat_grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_seeded_differently_are_caught_or_repaired():
+    from oracle import kan_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_total = 64
+    procs = [ctx.Process(target=_worker_mismatched, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(raised for _, raised, _, _ in results)       # both ranks learn of the mismatch
+    layers = O.random_layers([2, 8, 1], 5, seed=3)          # rank 0's values win
+    x = torch.rand(n_total, 2, generator=torch.Generator().manual_seed(4))
+    single = OracleStep(layers, "silu")
+    loss = float(single(x))
+    for _, _, l, g in results:
+        assert abs(l - loss) <= 2e-6 * abs(loss)
+        assert (g - single.flat_grad).abs().max() <= 2e-6 * single.flat_grad.abs().max()
+
+
 @pytest.mark.parametrize("n_total", [64, 101])
 def test_two_rank_step_equals_single_process(n_total):
     from oracle import kan_oracle as O
