@@ -85,6 +85,18 @@ size_t pdekan_layer_workspace_bytes(const PdekanLayer* layer, int64_t n, int32_t
 int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n,
                          int32_t n_dir, int32_t n_second, void* ws, size_t ws_bytes, void* stream);
 
+/* pdekan_layer_forward without a workspace argument.  No counterpart in the reference: it is for callers that
+ * can neither allocate device memory nor keep a workspace around - code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The packed weight tables live in a device array built into the
+ * library (PDEKAN_NOALLOC_SCRATCH_BYTES per GPU, held from library load to process end); the call allocates and
+ * frees nothing.  A layer whose tables exceed that size is refused with PDEKAN_ERR_WORKSPACE (a 128 -> 128 layer
+ * at grid 10 fits; 256 -> 256 at grid 20 does not).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams or threads) race; calls on one stream are ordered.  The first call on
+ * a device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+#define PDEKAN_NOALLOC_SCRATCH_BYTES (8u << 20)
+int pdekan_layer_forward_noalloc(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n,
+                                 int32_t n_dir, int32_t n_second, void* stream);
+
 /* What loss.backward() does through that forward (run1.py:225): given the
  * cotangent gy_jet[N][out][J], write gx_jet[N][in][J] (skipped if NULL) and
  * the parameter gradients (skipped if grads is NULL; added to the existing

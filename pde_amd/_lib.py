@@ -51,6 +51,8 @@ SIGNATURES = {
     "pdekan_layer_forward": (ctypes.c_int, [ctypes.POINTER(PdekanLayer), ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p]),
+    "pdekan_layer_forward_noalloc": (ctypes.c_int, [ctypes.POINTER(PdekanLayer), ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "pdekan_layer_backward": (ctypes.c_int, [ctypes.POINTER(PdekanLayer), ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                              ctypes.POINTER(PdekanLayerGrad), ctypes.c_int32, ctypes.c_void_p,

@@ -5,10 +5,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 #include "../../include/pdekan.h"
 #include "kan_launch.h"
+
+// Built-in scratch of pdekan_layer_forward_noalloc (see scratch_of_current_device below).
+static __device__ __align__(256) unsigned char scratch[PDEKAN_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -296,6 +300,55 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
   return ws ? c.ok : true;
 }
 
+int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
+                       int32_t n_second, void* ws, size_t ws_bytes, void* stream) {
+  pdekan::LayerView L;
+  int rc = to_view(layer, L);
+  if (rc) return rc;
+  if (!x_jet || !y_jet || n < 1) return fail(PDEKAN_ERR_ARG, "layer_forward: bad arguments");
+  if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  Carver c(ws, ws_bytes);
+  float* wp = c.take(L.packed_floats());
+  float* wt = c.take(L.packed_floats());
+  const size_t wf = win_floats(n_dir, n_second, L);
+  float* win = wf ? c.take(wf) : nullptr;
+  float* ginfo = c.take(L.I);
+  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  pdekan::launch_grid_info(L, ginfo, st);
+  L.ginfo = ginfo;
+  pdekan::launch_pack_weights(L, wp, wt, st);
+  if (win) pdekan::launch_pack_window(L, wp, win, st);
+  return run_forward(n_dir, n_second, L, x_jet, wt, win, y_jet, n, st);
+}
+
+// ---- built-in scratch of pdekan_layer_forward_noalloc ------------------------------------------------------
+// Device memory the library owns from load time on (no hipMalloc, ever): the packed weight tables of ONE layer
+// forward.  Every GPU the library is loaded on holds its own copy of the array at its own address; `scratch` is
+// only the host-side handle of the symbol, so the address is asked for once per device (with that device current)
+// and host code uses that pointer, never the array's name.  Every table in it is rewritten in full by the packing
+// kernels of each call, so nothing has to be cleared between calls.
+constexpr size_t kScratchBytes = PDEKAN_NOALLOC_SCRATCH_BYTES;
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
+int scratch_of_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices) return fail(PDEKAN_ERR_ARG, "device index %d out of range", dev);
+  void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));       // the same address whichever thread asks first
+    if (e != hipSuccess || !p) return fail(PDEKAN_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+    if ((uintptr_t)p & 255) return fail(PDEKAN_ERR_HIP, "built-in scratch is not 256-byte aligned");
+    g_scratch_ptr[dev].store(p, std::memory_order_release);
+  }
+  *out = p;
+  return PDEKAN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -321,25 +374,26 @@ size_t pdekan_layer_workspace_bytes(const PdekanLayer* layer, int64_t n, int32_t
 
 int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
                          int32_t n_second, void* ws, size_t ws_bytes, void* stream) {
+  return layer_forward_impl(layer, x_jet, y_jet, n, n_dir, n_second, ws, ws_bytes, stream);
+}
+
+int pdekan_layer_forward_noalloc(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
+                                 int32_t n_second, void* stream) {
   pdekan::LayerView L;
   int rc = to_view(layer, L);
   if (rc) return rc;
-  if (!x_jet || !y_jet || n < 1) return fail(PDEKAN_ERR_ARG, "layer_forward: bad arguments");
   if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
-  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
-  Carver c(ws, ws_bytes);
-  float* wp = c.take(L.packed_floats());
-  float* wt = c.take(L.packed_floats());
-  const size_t wf = win_floats(n_dir, n_second, L);
-  float* win = wf ? c.take(wf) : nullptr;
-  float* ginfo = c.take(L.I);
-  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
-  hipStream_t st = (hipStream_t)stream;
-  pdekan::launch_grid_info(L, ginfo, st);
-  L.ginfo = ginfo;
-  pdekan::launch_pack_weights(L, wp, wt, st);
-  if (win) pdekan::launch_pack_window(L, wp, win, st);
-  return run_forward(n_dir, n_second, L, x_jet, wt, win, y_jet, n, st);
+  // the packed tables do not depend on n: size them for one point
+  const size_t need = layer_ws_floats(n_dir, n_second, L, 1) * sizeof(float);
+  if (need > kScratchBytes)
+    return fail(PDEKAN_ERR_WORKSPACE,
+                "layer_forward_noalloc: a %d -> %d layer at grid %d needs %zu bytes of packed tables, the built-in "
+                "scratch holds %zu (PDEKAN_NOALLOC_SCRATCH_BYTES); use pdekan_layer_forward with a workspace",
+                L.I, L.O, L.G, need, kScratchBytes);
+  void* ptr = nullptr;
+  rc = scratch_of_current_device(&ptr);
+  if (rc) return rc;
+  return layer_forward_impl(layer, x_jet, y_jet, n, n_dir, n_second, ptr, kScratchBytes, stream);
 }
 
 int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const float* gy_jet, int64_t n,
