@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdekan.so")
-SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "pdekan_api.hip"]
+SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "kan_f16.hip", "pdekan_api.hip"]
 INCLUDE = os.path.join(HERE, "..", "include")
 ARCH = "gfx950"
 

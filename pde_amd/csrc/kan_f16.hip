@@ -1,0 +1,873 @@
+// Hidden KAN layers on the fp16 matrix cores of gfx950 with fp32 accuracy, J = 4
+// jets per scalar (value, d/dS, d/dt, d2/dS2): forward, input-jet gradients and
+// weight gradients of layers whose knot rows are equally spaced or nearly so.
+//
+// Reference computation: KANLinear.forward (efficient_kan/kan.py:153-166) and its
+// autograd backward, on jets (the derivatives run1.py:121-124 take with jacrev /
+// hessian).
+//
+// Split operands.  Every fp32 operand x of the three contractions
+//   forward        Y [(p,j)][o]  = sum_k E[(p,j)][k] * W[o][k]
+//   input grads    gE[(p,j)][k]  = sum_o gY[(p,j)][o] * W[o][k]     (+ chain rule through the basis)
+//   weight grads   gW[k][o]      = sum_(p,j) E[(p,j)][k] * gY[(p,j)][o]
+// (k = (input feature, column): the 4 live cubic bases of the feature + its base-activation column, the other
+// columns of the feature zero) is first multiplied by a power of two that brings its tensor's largest magnitude
+// just under 2^13 and then cut into two fp16 pieces, hi = fp16(x) (round to nearest) and lo = fp16(x - hi) (the
+// subtraction is exact in fp32).  hi + lo carries 22 significant bits of x wherever |x| is within 2^-16 of the
+// tensor's maximum, and an absolute error below 2^-38 of that maximum elsewhere (fp16 subnormals).  A product is
+//     hi*hi + hi*lo + lo*hi
+// three v_mfma_f32_16x16x32_f16 whose fp16 x fp16 products are exact in the fp32 accumulator; the term left out
+// is below 2^-22 |a b|.  The powers of two are divided out of the fp32 result (exact).  Per-jet scales: the jets
+// of a tensor differ by orders of magnitude (a second derivative against a value), so every jet slot j has its
+// own scale wherever the slot is a row index of the contraction; where it is summed over (weight gradients) the
+// product of the two operands' scales is kept the same for every j.
+// The maxima come from the kernels that produced the tensors (an epilogue of the producing kernel, or
+// jet_absmax_kernel), as float bit patterns combined with integer atomic max: the result does not depend on
+// the order of the atomics, so everything stays bitwise reproducible.
+//
+// Matrix work per fp32-accurate product: 3/16 of the fp32 matrix time (the fp32 MFMA runs at 1/16 of the fp16
+// rate), against 6/16 for the three-piece bf16 cut, and dense over the G+4 columns of a feature where the
+// vector-ALU kernels of kan_sparse.hip do 5: at grid 10 that is 3 * 14 / (16 * 5) = 0.53 of their ALU time.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "kan_math.h"
+#include "kan_launch.h"
+
+namespace pdekan {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kF16Target = 13;               // scaled maxima sit in [2^12, 2^13): 8x headroom under fp16's 65504
+constexpr int kKnotPadU = 28;                // staged knot row, equally spaced: G+7 knots + 1/h, G <= 20
+constexpr int kKnotPadN = 36;                // nearly equally spaced: 3 + 4 repeated end knots around the G+7 knots
+
+// ---- scales ---------------------------------------------------------------------------------------------
+// 2^k with bound * 2^k in [2^(target-1), 2^target); bound = 0 or denormal gives the largest scale allowed
+__device__ __forceinline__ float pow2_scale(float bound, int target = kF16Target) {
+  const int e = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;
+  int k = target - 1 - e;
+  k = k > 96 ? 96 : (k < -96 ? -96 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+__device__ __forceinline__ float rcp_pow2(float s) {      // exact reciprocal of a power of two
+  return __uint_as_float((254u << 23) - __float_as_uint(s));
+}
+
+// Upper bounds of the expanded jets E[(p, j)][k] of a layer from the per-jet maxima of its input jets:
+//   E0 = B or act(a0);  E1 = phi' a1;  E2 = phi' a2;  E3 = phi'' a1^2 + phi' a3,   |B'| <= 1/h, |B''| <= 2/h^2,
+//   |silu'| <= 1.1, |silu''| <= 0.5 (identity: 1, 0).
+struct JetScales { float s[4]; };
+__device__ __forceinline__ JetScales expanded_jet_scales(const unsigned* amax, float inv_h_max) {
+  const float a0 = __uint_as_float(amax[0]), a1 = __uint_as_float(amax[1]), a2 = __uint_as_float(amax[2]),
+              a3 = __uint_as_float(amax[3]);
+  const float c1 = fmaxf(1.1f, 1.5f * inv_h_max), c2 = fmaxf(0.5f, 3.0f * inv_h_max * inv_h_max);
+  JetScales r;
+  r.s[0] = pow2_scale(fmaxf(1.0f, a0));
+  r.s[1] = pow2_scale(c1 * a1);
+  r.s[2] = pow2_scale(c1 * a2);
+  r.s[3] = pow2_scale(c2 * a1 * a1 + c1 * a3);
+  return r;
+}
+
+// largest |1/h| over the layer's features (ginfo holds 1/h or -1/h), the same in every lane
+__device__ __forceinline__ float max_inv_h(const float* ginfo, int I, int lane) {
+  float m = 0.0f;
+  for (int i = lane; i < I; i += 64) m = fmaxf(m, fabsf(ginfo[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  return m;
+}
+
+// out[j] = max(out[j], bits of max |t[e][j]|) over e < n4: per-jet maxima of a jet tensor laid out [...][4]
+__global__ void jet_absmax_kernel(const f32x4* __restrict__ t, int64_t n4, unsigned* __restrict__ out) {
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = t[e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicMax(out + j, __float_as_uint(m[j]));
+  }
+}
+
+// out[0] = max(out[0], bits of max |w[e]|)
+__global__ void absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.0f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[e]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// per-jet maxima of this lane's values -> wave maximum -> one integer atomic max per jet and wave
+__device__ __forceinline__ void publish_jet_max(f32x4 m, unsigned* out, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], d));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicMax(out + j, __float_as_uint(m[j]));
+  }
+}
+
+// ---- the two-piece cut ----------------------------------------------------------------------------------
+// (x0, x1) -> one dword of each plane, x0 in the low half: hi = fp16(x) to nearest, lo = fp16(x - hi) (fp32
+// subtraction inside the mixed-precision fma, rounded once to fp16)
+__device__ __forceinline__ void split_pair16(float x0, float x1, unsigned& h, unsigned& l) {
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+}
+
+struct Planes16 { u32x2 h, l; };                           // the 4 jets of one scalar, two planes
+
+__device__ __forceinline__ Planes16 split_jet16(f32x4 v) {
+  Planes16 r;
+  unsigned h0, l0, h1, l1;
+  split_pair16(v[0], v[1], h0, l0);
+  split_pair16(v[2], v[3], h1, l1);
+  r.h = (u32x2){h0, h1};
+  r.l = (u32x2){l0, l1};
+  return r;
+}
+
+// ---- expansion of one (point, feature) pair ---------------------------------------------------------------
+struct FeatGrid { float g0, glast, inv_h; };
+struct PairCols { f32x4 col[5]; int c0; };                 // 4 live spline columns c0..c0+3 and the base column
+
+// GEN = false: knots equally spaced (fixed polynomial pieces, interval from the quotient alone); GEN = true:
+// nearly so (general triangle on the knots around the quotient guess; the row is staged with repeated end knots)
+template <int ACT, bool GEN>
+__device__ __forceinline__ void expand_scaled(const float* knots, int nk, const FeatGrid& fg, f32x4 jet,
+                                              const JetScales& sc, PairCols& out) {
+  Basis bs;
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
+  const Act av = eval_act(ACT, jet[0]);
+  const float a1 = jet[1] * sc.s[1], a2 = jet[2] * sc.s[2], a3 = jet[3] * sc.s[3], q3 = jet[1] * jet[1] * sc.s[3];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    out.col[m] = (f32x4){bs.b[m] * sc.s[0], bs.d1[m] * a1, bs.d1[m] * a2, bs.d2[m] * q3 + bs.d1[m] * a3};
+  out.col[4] = (f32x4){av.f0 * sc.s[0], av.f1 * a1, av.f1 * a2, av.f2 * q3 + av.f1 * a3};
+  out.c0 = bs.c0;
+}
+
+// ---- E tile of a wave in LDS: [2 planes][ROWS columns][RW words], a row = one expanded column k holding the
+// (p, j) of the wave's points as fp16 (2 words per point) -------------------------------------------------------
+// 16 points x 4 jets x fp16 = 128 bytes + 32 bytes (dump slot).  40 words: the 8 consecutive rows that a 32-lane group
+// of a transposed read touches (8 words each) start 40 * d mod 64 = {0, 40, 16, 56, 32, 8, 48, 24} banks apart: no conflicts.
+constexpr int kRowWords = 40;
+
+// Order of the expanded columns inside a k-step of 32 (the same for the A operand's transposed reads and the packed
+// B operand): element e = 0..7 of lane group kb = 0..3 is column 16*(kb>>1) + 8*(e>>2) + 4*(kb&1) + (e&3) of the k-step, so
+// that the two lane groups that share an LDS access (kb = 0, 1 or 2, 3) read 8 consecutive rows of the tile.
+__host__ __device__ constexpr int kstep_col(int kb, int e) { return 16 * (kb >> 1) + 8 * (e >> 2) + 4 * (kb & 1) + (e & 3); }
+
+// park a pair's planes: clear the columns written one stage earlier, write the live ones
+template <int C1, int PLANE>
+__device__ __forceinline__ void park_pair16(unsigned* base, unsigned* dump, const Planes16 (&pp)[5], int c0, int& prev_c0) {
+  constexpr int C = C1 - 1;
+  const u32x2 zero = {0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = prev_c0 + m;
+    unsigned* dst = (c >= 0 && c < C) ? base + c * kRowWords : dump;
+    *reinterpret_cast<u32x2*>(dst) = zero;
+    *reinterpret_cast<u32x2*>(dst + PLANE) = zero;
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = (m < 4) ? c0 + m : C;
+    unsigned* dst = (m == 4 || (c >= 0 && c < C)) ? base + c * kRowWords : dump;
+    *reinterpret_cast<u32x2*>(dst) = pp[m].h;
+    *reinterpret_cast<u32x2*>(dst + PLANE) = pp[m].l;
+  }
+  prev_c0 = c0;
+}
+
+// A operand of one (k-step, m-tile): 8 columns of this lane's (p, j), transposed out of the E tile by the
+// hardware (a 16-lane group reads 4 columns x 16 (p, j), every lane gets its (p, j) of the 4 columns)
+struct ATile16 { u32x4 h, l; };
+
+__device__ __forceinline__ u32x4 tr_read8(const unsigned* row0, const unsigned* row1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)row0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)row1);
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  return (u32x4){a.x, a.y, b.x, b.y};
+}
+
+template <int PLANE>
+__device__ __forceinline__ ATile16 read_atile16(const unsigned* sE, int off0, int off1, int m) {
+  ATile16 t;
+  const unsigned* p0 = sE + off0 + 8 * m;    // 16 (p, j) per m-tile = 8 words
+  const unsigned* p1 = sE + off1 + 8 * m;
+  t.h = tr_read8(p0, p1);
+  t.l = tr_read8(p0 + PLANE, p1 + PLANE);
+  return t;
+}
+
+// acc += a * b to fp32 accuracy: the two cross terms first, the leading term last
+__device__ __forceinline__ f32x4 mfma3(f32x4 c, u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl) {
+  const f16x8 Ah = __builtin_bit_cast(f16x8, ah), Al = __builtin_bit_cast(f16x8, al);
+  const f16x8 Bh = __builtin_bit_cast(f16x8, bh), Bl = __builtin_bit_cast(f16x8, bl);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c, 0, 0, 0);
+  return c;
+}
+
+// the same for the 4 output tiles of one k-step, product by product: consecutive matrix instructions write different
+// accumulators (a dependent one would hold the wave's issue until its predecessor has left the pipe)
+__device__ __forceinline__ void mfma3x4(f32x4 (&acc)[4], u32x4 ah, u32x4 al, const u32x4 (&bh)[4], const u32x4 (&bl)[4]) {
+  const f16x8 Ah = __builtin_bit_cast(f16x8, ah), Al = __builtin_bit_cast(f16x8, al);
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, __builtin_bit_cast(f16x8, bh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, __builtin_bit_cast(f16x8, bl[n]), acc[n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, __builtin_bit_cast(f16x8, bh[n]), acc[n], 0, 0, 0);
+}
+
+// scheduling hint for a fenced region: CNT matrix instructions, each followed by up to PER other instructions
+template <int CNT, int PER>
+__device__ __forceinline__ void interleave() {
+#pragma unroll
+  for (int k = 0; k < CNT; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x3b2, PER, 0);         // VALU / VMEM / DS
+  }
+}
+
+// ==========================================================================================================
+// W planes.  CP = columns per feature in the K index (C1 rounded up so that 4 features are whole k-steps of 32:
+// 14 -> 16, 24 -> 24), a stage = 4 features = KS = CP/8 k-steps.
+//   forward (B operand, K = columns):   wplf[O/64][I/4 stages][KS][4 n][2 planes][64 lanes] x 16 bytes,
+//     lane (r = lane&15, kb = lane>>4) holds output 64*by + 16n + r, columns 32*ks + kstep_col(kb, 0 .. 7) of the stage
+//   input gradients (B operand, K = outputs): wplb[O/64][I/4 stages][2 ks][NB = CP/4 n][2 planes][64 lanes] x 16 bytes,
+//     lane (r, kb) holds column 16n + r of the stage, outputs 64*by + 32*ks + 8*kb .. + 7
+// both scaled by the power of two that brings max |w| under 2^13.
+// ==========================================================================================================
+template <int CP>
+__global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsigned* __restrict__ wmax,
+                                      u32x4* __restrict__ wplf, u32x4* __restrict__ wplb, int I, int O, int C1) {
+  constexpr int KS = CP / 8, NB = CP / 4;
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  const int nst = I / 4;
+  const int total_f = (O / 64) * nst * KS * 4 * 64;
+  const int total_b = (O / 64) * nst * 2 * NB * 64;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total_f + total_b; t += gridDim.x * blockDim.x) {
+    float v[8];
+    u32x4* dst;
+    if (t < total_f) {
+      const int lane = t & 63, n = (t >> 6) & 3;
+      const int ks = (t >> 8) % KS, st = ((t >> 8) / KS) % nst, by = (t >> 8) / (KS * nst);
+      const int o = by * 64 + n * 16 + (lane & 15), kb = lane >> 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 32 + kstep_col(kb, e);
+        const int f = st * 4 + k / CP, c = k % CP;
+        v[e] = (c < C1) ? wp[((size_t)o * I + f) * C1 + c] * sw : 0.0f;
+      }
+      dst = wplf + ((((size_t)(by * nst + st) * KS + ks) * 4 + n) * 2) * 64 + lane;
+    } else {
+      const int u = t - total_f;
+      const int lane = u & 63, n = (u >> 6) % NB;
+      const int ks = ((u >> 6) / NB) & 1, st = ((u >> 6) / (NB * 2)) % nst, by = (u >> 6) / (NB * 2 * nst);
+      const int k = n * 16 + (lane & 15), kb = lane >> 4;
+      const int f = st * 4 + k / CP, c = k % CP;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int o = by * 64 + ks * 32 + kb * 8 + e;
+        v[e] = (c < C1) ? wp[((size_t)o * I + f) * C1 + c] * sw : 0.0f;
+      }
+      dst = wplb + ((((size_t)(by * nst + st) * 2 + ks) * NB + n) * 2) * 64 + lane;
+    }
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_pair16(v[2 * e], v[2 * e + 1], h[e], l[e]);
+    dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
+    dst[64] = (u32x4){l[0], l[1], l[2], l[3]};
+  }
+}
+
+// ==========================================================================================================
+// forward.  M = (point, jet): 16 rows = 4 points, N = 16 outputs, K = 32 columns.  Wave = 16 points x 64 outputs
+// (16 accumulator tiles) over all features, a stage of 4 features (KS k-steps, 4*KS regions of 12 matrix
+// instructions) at a time; the pairs of the next stage are expanded, cut and parked between the matrix
+// instructions of this one.  B operands (W planes) go from L2 straight into registers one stage ahead, A operands
+// come out of the wave's E tile by transposed reads two regions ahead.  No block barrier in the loop.
+// Runs when every feature of the layer has equally spaced knots (GEN = false) / at least nearly so and not all
+// equally (GEN = true); otherwise it returns at once and fwd_sparse_kernel, launched beside it, does the layer.
+// ==========================================================================================================
+struct WTiles16 { u32x4 h[4], l[4]; };                     // B operands of one k-step: [n]
+
+__device__ __forceinline__ void load_w16(WTiles16& W, const u32x4* __restrict__ src, int lane, int n) {
+  const u32x4* p = src + (n * 2) * 64 + lane;
+  W.h[n] = p[0];
+  W.l[n] = p[64];
+}
+
+template <int C1, int ACT, bool GEN>
+struct FwdF16 {
+  static constexpr int CP = (C1 + 7) / 8 * 8;
+  static constexpr int KS = CP / 8;                        // k-steps of 32 columns per stage of 4 features
+  static constexpr int NR = 4 * KS;                        // regions (k-step, m-tile) per stage
+  static constexpr int ROWS = 4 * C1 + 1;                  // + one row of zeros for the pad columns
+  static constexpr int PLANE = ROWS * kRowWords;
+  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int nk = C1 + 3;
+  static constexpr int kStepVecs = 4 * 2 * 64;             // u32x4 per k-step of W planes
+  static constexpr int kStageVecs = KS * kStepVecs;
+
+  // One stage.  On entry the E tile holds this stage, cur / nxt its first two A operands, W0 the B operands of its
+  // first k-step and xraw the input jets of the NEXT stage's pairs.  Two waves share a SIMD, so the B operands are
+  // fetched one k-step (4 regions) ahead only, into the buffer the k-step before has just finished with.
+  //   region 0            basis of the next stage's pairs (scaled)
+  //   region 1            fetch the input jets of the stage after the next; cut columns 0, 1
+  //   region 2            cut columns 2, 3, 4
+  //   region NR-2         park the next stage's planes (every A operand of this stage has been requested)
+  // wsrc: W planes of this stage; wnext: of the next stage (its first k-step is fetched during the last one here).
+  template <bool FLIP>
+  static __device__ __forceinline__ void stage(f32x4 (&acc)[4][4], WTiles16& Wa, WTiles16& Wb, ATile16& cur,
+                                               ATile16& nxt, f32x4& xraw, unsigned* sE, const float* knots_next,
+                                               const JetScales& sc, int& prev_c0, const u32x4* __restrict__ wsrc,
+                                               const u32x4* __restrict__ wnext,
+                                               const char* __restrict__ xnext2, const int (&aoff)[KS][2], int lane) {
+    const int p_local = lane & 15, f_local = lane >> 4;
+    PairCols pj;
+    Planes16 pp[5];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int ks = i >> 2, m = i & 3;
+      const bool odd = ((ks & 1) != 0) != FLIP;            // which buffer holds this k-step
+      WTiles16& Wc = odd ? Wb : Wa;
+      WTiles16& Wn = odd ? Wa : Wb;
+      // one of the 4 output tiles of the next k-step's B operands (both planes)
+      load_w16(Wn, (ks + 1 < KS) ? wsrc + (ks + 1) * kStepVecs : wnext, lane, m);
+      if (i == 0) {
+        const FeatGrid fg = {knots_next[0], knots_next[nk - 1], fabsf(knots_next[GEN ? nk + 4 : nk])};
+        expand_scaled<ACT, GEN>(knots_next, nk, fg, xraw, sc, pj);
+      }
+      if (i == 1) {
+        xraw = *reinterpret_cast<const f32x4*>(xnext2);
+        pp[0] = split_jet16(pj.col[0]);
+        pp[1] = split_jet16(pj.col[1]);
+      }
+      if (i == 2) {
+        pp[2] = split_jet16(pj.col[2]);
+        pp[3] = split_jet16(pj.col[3]);
+        pp[4] = split_jet16(pj.col[4]);
+      }
+      if (i == NR - 2) {
+        // lgkmcnt counts to 15 only: behind the writes below, a wait for any OLDER read would have to sit out most
+        // of the writes too.  The reads in flight were requested a region or more ago: retire them first.
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0)
+        unsigned* base = sE + (f_local * C1) * kRowWords + p_local * 2;
+        park_pair16<C1, PLANE>(base, sE + (f_local * C1) * kRowWords + 32, pp, pj.c0, prev_c0);
+      }
+      const int t2 = (i + 2) % NR;             // the last two regions request regions 0 and 1 of the next stage
+      const ATile16 far = read_atile16<PLANE>(sE, aoff[t2 >> 2][0], aoff[t2 >> 2][1], t2 & 3);
+      mfma3x4(acc[m], cur.h, cur.l, Wc.h, Wc.l);
+      cur = nxt;
+      nxt = far;
+      if (i == 0) interleave<12, 8>(); else interleave<12, 4>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 2)
+fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+               const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
+               const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
+  using F = FwdF16<C1, ACT, GEN>;
+  constexpr int KS = F::KS, KP = F::KP, nk = F::nk, CP = F::CP;
+  constexpr int kWaveWords = 2 * F::PLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // block-uniform: every feature's knots at least nearly equally spaced; GEN = false takes the layer when all are equal
+  {
+    bool near = true, equal = true;
+    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+      const float gi = ginfo[i < I ? i : 0];
+      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+    }
+    if (!near || equal == GEN) return;
+  }
+  float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + I * KP + wave * kWaveWords;   // this wave's E tile
+  if constexpr (GEN) {                       // [g_0 x3][the nk knots][g_last x4][1/h]
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  for (int idx = lane; idx < kWaveWords; idx += 64) sE[idx] = 0u;
+  const JetScales sc = expanded_jet_scales(amax_in, max_inv_h(ginfo, I, lane));
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  __syncthreads();
+
+  const int r = lane & 15, kb = lane >> 4, p_local = lane & 15, f_local = lane >> 4;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  const int o0 = blockIdx.y * 64;
+  const int nst = I / 4;
+  // E tile rows of this lane's transposed reads: lane 4q+p of a 16-lane group addresses row (column) q, (p, j) 4p .. 4p+3
+  int aoff[KS][2];
+  {
+    const int q_ = (lane & 15) >> 2, p_ = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int col = ks * 32 + kstep_col(kb, half * 4 + q_);
+        const int row = ((col % CP) < C1) ? (col / CP) * C1 + (col % CP) : F::ROWS - 1;
+        aoff[ks][half] = row * kRowWords + 2 * p_;
+      }
+  }
+  int64_t prow = P0 + p_local;                                              // this lane's point when it expands
+  if (prow > N - 1) prow = N - 1;
+  const char* xrow = reinterpret_cast<const char*>(a + prow * I + f_local);
+  const u32x4* wbase = wpl + (size_t)blockIdx.y * nst * F::kStageVecs;
+  const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (P0 < N) {                              // wave-uniform; no barrier below
+    WTiles16 WA, WB;
+    int prev_c0 = -100;
+    f32x4 xraw;
+    {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
+      xraw = *reinterpret_cast<const f32x4*>(xrow + 64);                    // 4 features x 16 bytes per stage
+      const FeatGrid fg = {kbase[0], kbase[nk - 1], fabsf(kbase[GEN ? nk + 4 : nk])};
+      PairCols pj;
+      Planes16 pp[5];
+      expand_scaled<ACT, GEN>(kbase, nk, fg, x0, sc, pj);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) pp[m] = split_jet16(pj.col[m]);
+      unsigned* base = sE + (f_local * C1) * kRowWords + p_local * 2;
+      park_pair16<C1, F::PLANE>(base, sE + (f_local * C1) * kRowWords + 32, pp, pj.c0, prev_c0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) load_w16(WA, wbase, lane, n);
+    }
+    ATile16 cur = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 0);
+    ATile16 nxt = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 1);
+    for (int s = 0; s < nst; s += 2) {
+      // stages past the end: any valid data, expanded and parked but never multiplied
+      const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : 0, s3 = (s + 3 < nst) ? s + 3 : 0;
+      F::template stage<false>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s1 * KP, sc, prev_c0,
+                               wbase + (size_t)s * F::kStageVecs, wbase + (size_t)s1 * F::kStageVecs,
+                               xrow + (size_t)s2 * 64, aoff, lane);
+      F::template stage<(KS & 1) != 0>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s2 * KP, sc, prev_c0,
+                                       wbase + (size_t)s1 * F::kStageVecs, wbase + (size_t)s2 * F::kStageVecs,
+                                       xrow + (size_t)s3 * 64, aoff, lane);
+    }
+    // D[(p, j)][output]: this lane holds the 4 jets of point 4m + kb for output 16n + r
+    f32x4 inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[j] * sw);
+    f32x4 vmax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int64_t p = P0 + 4 * m + kb;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 v = acc[m][n] * inv;
+        if (p < N) {
+          y[p * O + o0 + 16 * n + r] = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(v[j]));
+        }
+      }
+    }
+    if (amax_out) publish_jet_max(vmax, amax_out, lane);
+  }
+}
+
+// ==========================================================================================================
+// input-jet gradients.  gE[(p, j)][k] = sum_o gY[(p, j)][o] * W[o][k]: M = (point, jet), K = 64 outputs (2 k-steps),
+// N = 16 columns.  Wave = 16 points; the A operands (the wave's gY rows, cut into planes once) stay in registers,
+// the B operands (W planes) stream from L2 one column tile at a time, two regions ahead.  A stage = 4 features =
+// NB column tiles x 2 k-steps = 2*NB regions of 12 matrix instructions; its 16 x 4*CP tile of gE is parked in
+// LDS, every (point, feature) lane pulls the 4+1 live columns of its pair and applies the chain rule through
+// B', B'', B''' and the activation derivatives - during the matrix instructions of the NEXT stage.
+// Layers wider than 64 outputs are walked 64 outputs at a time; each pass adds its share to the gradients the
+// same lane stored at the same address in the pass before (the chain rule is linear in gE).
+// ==========================================================================================================
+struct WTile16 { u32x4 h, l; };
+
+template <int C1, int ACT, bool GEN>
+struct BwiF16 {
+  static constexpr int CP = (C1 + 7) / 8 * 8;
+  static constexpr int NB = CP / 4;                        // column tiles of 16 per stage of 4 features
+  static constexpr int NR = 2 * NB;                        // regions (k-step, column tile) per stage
+  static constexpr int ROW = 4 * CP * 4 + 4;               // words per point in the parked gE tile (+4: bank spread)
+  static constexpr int GROW = 64 * 4 + 4;                  // words per point of the staged raw gY rows
+  static constexpr int TILE = 16 * (ROW > GROW ? ROW : GROW);
+  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int nk = C1 + 3;
+  static constexpr int kStageVecs = 2 * NB * 2 * 64;       // u32x4 per stage of W planes (input-gradient layout)
+};
+
+// basis with the third derivative for the chain rule: the interval is settled by comparisons against the knots
+template <int ACT, bool GEN>
+__device__ __forceinline__ void eval_pair_d3(const float* knots, int nk, const FeatGrid& fg, float x, Basis& bs, Act& av) {
+  if constexpr (GEN) eval_basis_near_uniform<true>(knots, nk, fg.g0, fg.glast, fg.inv_h, x, bs);
+  else eval_basis_uniform_straight<true>(knots, nk, fg.inv_h, x, bs);
+  av = eval_act(ACT, x);
+}
+
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 2)
+bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                     const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
+                     int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
+                     unsigned* __restrict__ cot_out) {
+  using F = BwiF16<C1, ACT, GEN>;
+  constexpr int NB = F::NB, NR = F::NR, KP = F::KP, nk = F::nk, CP = F::CP, ROW = F::ROW, GROW = F::GROW;
+  constexpr int C = C1 - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  {
+    bool near = true, equal = true;
+    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+      const float gi = ginfo[i < I ? i : 0];
+      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+    }
+    if (!near || equal == GEN) return;
+  }
+  float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
+  float* sD = sK + I * KP + wave * F::TILE;                                 // this wave's tile
+  if constexpr (GEN) {
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  // per-jet scales of the cotangent rows, the weights' scale, and what divides both out of gE
+  float tj[4];
+  f32x4 inv;
+  {
+    const float sw = pow2_scale(__uint_as_float(wmax[0]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tj[j] = pow2_scale(__uint_as_float(cot_in[j])); inv[j] = rcp_pow2(tj[j] * sw); }
+  }
+  __syncthreads();
+
+  const int r = lane & 15, kb = lane >> 4, p_local = lane & 15, f_local = lane >> 4;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (P0 >= N) return;                        // wave-uniform; no barrier below
+  const int nst = I / 4;
+  int64_t prow = P0 + p_local;
+  const bool live_pt = prow < N;
+  if (!live_pt) prow = N - 1;
+  const char* xrow = reinterpret_cast<const char*>(a + prow * I + f_local);
+  f32x4* orow = ga + prow * I + f_local;
+  const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
+  const float my_t = tj[r & 3];               // this lane's A-operand row is jet r & 3 of point r >> 2 of the m-tile
+  f32x4 vmax = {0.f, 0.f, 0.f, 0.f};
+  const int npass = O / 64;
+
+  for (int ob = 0; ob < npass; ++ob) {
+    // ---- the wave's gY rows of this output block -> A operands in registers ----
+    u32x4 GAh[4][2], GAl[4][2];
+    {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {          // 16 points x 64 outputs x 16 bytes, 1 KiB per instruction
+        const int idx = lane + 64 * v, p = idx >> 6, o = idx & 63;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (P0 + p < N) g = gy[(P0 + p) * O + ob * 64 + o];
+        *reinterpret_cast<f32x4*>(sD + p * GROW + o * 4) = g;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float* src = sD + (4 * m + (r >> 2)) * GROW + (32 * ks + 8 * kb) * 4 + (r & 3);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = src[e * 4] * my_t;
+          unsigned h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair16(v[2 * e], v[2 * e + 1], h[e], l[e]);
+          GAh[m][ks] = (u32x4){h[0], h[1], h[2], h[3]};
+          GAl[m][ks] = (u32x4){l[0], l[1], l[2], l[3]};
+        }
+    }
+    const u32x4* wbase = wpl + (size_t)ob * nst * F::kStageVecs;
+    // region i of a stage: k-step i / NB, column tile i % NB; its B operand sits at wsrc + i * 128 + lane
+    WTile16 Wt[4];
+    auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
+    fetch_w(Wt[0], wbase);
+    fetch_w(Wt[1], wbase + 128);
+
+    f32x4 acc[4][NB];
+
+    // pipeline registers: the pair of the stage being multiplied (jet, basis) and of the stage before (gE columns)
+    f32x4 xcur = *reinterpret_cast<const f32x4*>(xrow), xnext = xcur;
+    if (nst > 1) xnext = *reinterpret_cast<const f32x4*>(xrow + 64);
+    f32x4 xprev = xcur, old = {0.f, 0.f, 0.f, 0.f};
+    Basis bprev;
+    Act aprev;
+    f32x4 dcol[5];
+    bool have_prev = false;
+
+    for (int s = 0; s <= nst; ++s) {           // one extra trip applies the chain rule of the last stage
+      const bool mul = s < nst;
+      const u32x4* wsrc = wbase + (size_t)(mul ? s : 0) * F::kStageVecs;
+      const u32x4* wnxt = wbase + (size_t)((s + 1 < nst) ? s + 1 : 0) * F::kStageVecs;
+      Basis bcur;
+      Act acur;
+      if (mul) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int ks = i / NB, n = i % NB;
+          {                                     // B operand of the region after the next
+            const int t = i + 2;
+            fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
+          }
+          if (i == 0 && have_prev) {            // chain rule of the stage before, on the columns read after its park
+            f32x4 out = {0.f, 0.f, 0.f, 0.f};
+            const float s2 = xprev[1] * xprev[1];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+              const float e1 = m < 4 ? bprev.d1[m & 3] : aprev.f1;
+              const float e2 = m < 4 ? bprev.d2[m & 3] : aprev.f2;
+              const float e3 = m < 4 ? bprev.d3[m & 3] : aprev.f3;
+              const f32x4 q = dcol[m] * inv;
+              out[0] += q[0] * e1 + (q[1] * xprev[1] + q[2] * xprev[2]) * e2 + q[3] * (s2 * e3 + xprev[3] * e2);
+              out[1] += q[1] * e1 + 2.0f * xprev[1] * q[3] * e2;
+              out[2] += q[2] * e1;
+              out[3] += q[3] * e1;
+            }
+            if (ob > 0) out += old;
+            if (live_pt) {
+              orow[(s - 1) * 4] = out;
+              if (ob == npass - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(out[j]));
+              }
+            }
+          }
+          if (i == 1) {                         // this stage's pair: basis, activation (kept for the next stage)
+            const FeatGrid fg = {kbase[4 * s * KP], kbase[4 * s * KP + nk - 1], fabsf(kbase[4 * s * KP + (GEN ? nk + 4 : nk)])};
+            eval_pair_d3<ACT, GEN>(kbase + 4 * s * KP, nk, fg, xcur[0], bcur, acur);
+            if (ob > 0) old = orow[s * 4];
+          }
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};   // the first k-step starts the sums (no separate clearing pass)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
+                                                               __builtin_bit_cast(f16x8, Wt[i & 3].h),
+                                                               ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                               __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                               __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
+          if (i == 0) interleave<12, 8>(); else interleave<12, 4>();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * n + r) * 4) = acc[m][n];
+          }
+        // the 4 + 1 live columns of this lane's pair (a column outside [0, C) reads the pad column: zero weight
+        // planes, so zero)
+        const float* drow = sD + p_local * ROW + (f_local * CP) * 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = bcur.c0 + m;
+          dcol[m] = (c >= 0 && c < C) ? *reinterpret_cast<const f32x4*>(drow + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        dcol[4] = *reinterpret_cast<const f32x4*>(drow + C * 4);
+        bprev = bcur; aprev = acur; xprev = xcur; have_prev = true;
+        xcur = xnext;
+        if (s + 2 < nst) xnext = *reinterpret_cast<const f32x4*>(xrow + (size_t)(s + 2) * 64);
+      } else {
+        // last trip: only the chain rule of the last stage
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        const float s2 = xprev[1] * xprev[1];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          const float e1 = m < 4 ? bprev.d1[m & 3] : aprev.f1;
+          const float e2 = m < 4 ? bprev.d2[m & 3] : aprev.f2;
+          const float e3 = m < 4 ? bprev.d3[m & 3] : aprev.f3;
+          const f32x4 q = dcol[m] * inv;
+          out[0] += q[0] * e1 + (q[1] * xprev[1] + q[2] * xprev[2]) * e2 + q[3] * (s2 * e3 + xprev[3] * e2);
+          out[1] += q[1] * e1 + 2.0f * xprev[1] * q[3] * e2;
+          out[2] += q[2] * e1;
+          out[3] += q[3] * e1;
+        }
+        if (ob > 0) out += old;
+        if (live_pt) {
+          orow[(s - 1) * 4] = out;
+          if (ob == npass - 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(out[j]));
+          }
+        }
+      }
+    }
+  }
+  if (cot_out) publish_jet_max(vmax, cot_out, lane);
+}
+
+// ==========================================================================================================
+// host side
+// ==========================================================================================================
+static bool f16_disabled() {
+  static const bool off = [] { const char* v = getenv("PDEKAN_DISABLE_F16"); return v && v[0] == '1'; }();
+  return off;
+}
+
+// layers the fp16 matrix kernels take (whether they run is settled on the device from the knot rows)
+bool f16_eligible(int D, int D2, const LayerView& L) {
+  if (D != 2 || D2 != 1 || f16_disabled()) return false;
+  if (L.G != 10 && L.G != 20) return false;
+  return L.I >= 8 && L.I % 8 == 0 && L.I <= 256 && L.O % 64 == 0 && L.O <= 256;
+}
+
+static int cp_of(const LayerView& L) { return (L.C1() + 7) / 8 * 8; }
+
+// floats of workspace for the W planes of a layer (forward layout, then input-gradient layout)
+size_t f16_wplane_floats(const LayerView& L) {
+  const size_t fwd = (size_t)L.O * L.I * cp_of(L);        // 2 planes x CP columns x fp16 = CP floats per (o, i)
+  return 2 * fwd;
+}
+
+void launch_absmax(const float* w, int64_t n, unsigned* out, hipStream_t st) {
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  absmax_kernel<<<blocks, 256, 0, st>>>(w, n, out);
+}
+
+void launch_jet_absmax(const float* t, int64_t elems, unsigned* out4, hipStream_t st) {
+  int64_t blocks = (elems + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  jet_absmax_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const f32x4*>(t), elems, out4);
+}
+
+// wp[O][I][C1] -> the two W plane images; wmax: bits of max |wp| (launch_absmax)
+void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st) {
+  u32x4* f = reinterpret_cast<u32x4*>(wpl);
+  u32x4* b = reinterpret_cast<u32x4*>(wpl + f16_wplane_floats(L) / 2);
+  const int cp = cp_of(L);
+  const int total = (L.O / 64) * (L.I / 4) * ((cp / 8) * 4 + 2 * (cp / 4)) * 64;
+  int blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (cp == 16) pack_wplanes16_kernel<16><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O, L.C1());
+  else pack_wplanes16_kernel<24><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O, L.C1());
+}
+
+template <typename Kern>
+static void allow_lds(Kern k, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int C1, int ACT, bool GEN>
+static void fwd_f16_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
+                           const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
+  using F = FwdF16<C1, ACT, GEN>;
+  auto k = fwd_f16_kernel<C1, ACT, GEN>;
+  const size_t lds = ((size_t)L.I * F::KP + 4 * 2 * F::PLANE) * 4;
+  allow_lds(k, lds);
+  dim3 g((unsigned)((N + 63) / 64), L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wpl),
+                         reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax, amax_out);
+}
+
+template <int C1>
+static void fwd_f16_variants(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
+                             const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
+  if (L.act == kActSiLU) {
+    fwd_f16_launch<C1, kActSiLU, false>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+    fwd_f16_launch<C1, kActSiLU, true>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  } else {
+    fwd_f16_launch<C1, kActIdentity, false>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+    fwd_f16_launch<C1, kActIdentity, true>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  }
+}
+
+// both variants on the same grid; the one that matches the layer's knot rows runs, the other returns at once
+void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
+                    const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
+  if (L.G == 10) fwd_f16_variants<14>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  else fwd_f16_variants<24>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+}
+
+template <int C1, int ACT, bool GEN>
+static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
+                           const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
+  using F = BwiF16<C1, ACT, GEN>;
+  auto k = bwd_input_f16_kernel<C1, ACT, GEN>;
+  const size_t lds = ((size_t)L.I * F::KP + 4 * F::TILE) * 4;
+  allow_lds(k, lds);
+  k<<<(unsigned)((N + 63) / 64), 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(gy),
+                                                 L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wplb),
+                                                 reinterpret_cast<f32x4*>(ga), N, L.I, L.O, cot_in, wmax, cot_out);
+}
+
+template <int C1>
+static void bwi_f16_variants(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
+                             const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
+  if (L.act == kActSiLU) {
+    bwi_f16_launch<C1, kActSiLU, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+    bwi_f16_launch<C1, kActSiLU, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  } else {
+    bwi_f16_launch<C1, kActIdentity, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+    bwi_f16_launch<C1, kActIdentity, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  }
+}
+
+// cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr
+void launch_bwd_input_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
+                          const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
+  const float* wplb = wpl + f16_wplane_floats(L) / 2;
+  if (L.G == 10) bwi_f16_variants<14>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  else bwi_f16_variants<24>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+}
+
+}  // namespace pdekan

@@ -58,9 +58,26 @@ bool sparse_eligible(int D, int D2, const LayerView& L);
 bool sparse_input_grad_eligible(int D, int D2, const LayerView& L);
 size_t sparse_table_floats(const LayerView& L);
 void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st);
-void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st);
+// skip_near_uniform: return at once when every knot row is (nearly) equally spaced - the fp16 matrix kernel launched
+// beside this one does the layer then
+void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
+                       bool skip_near_uniform = false);
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                             int64_t N, hipStream_t st);
+                             int64_t N, hipStream_t st, bool skip_near_uniform = false);
+
+// kan_f16.hip: hidden layers on the fp16 matrix cores with fp32 accuracy (two fp16 pieces per operand, three
+// products), J = 4 jets; for layers whose knot rows are all (nearly) equally spaced - decided on the device
+bool f16_eligible(int D, int D2, const LayerView& L);
+size_t f16_wplane_floats(const LayerView& L);
+void launch_absmax(const float* w, int64_t n, unsigned* out, hipStream_t st);               // out[0] = bits of max |w|
+void launch_jet_absmax(const float* t, int64_t elems, unsigned* out4, hipStream_t st);      // per-jet maxima of [elems][4]
+void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st);
+// amax_in: per-jet maxima of a (4 words); amax_out: where the per-jet maxima of y are combined into, or nullptr
+void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
+                    const unsigned* wmax, unsigned* amax_out, hipStream_t st);
+// cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr
+void launch_bwd_input_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
+                          const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st);
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);

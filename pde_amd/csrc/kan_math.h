@@ -212,8 +212,10 @@ KAN_HD void eval_basis_uniform_by_quotient(const KnotPtr g, int nk, float g0, fl
 // eval_basis runs on the 6 knots selected.  gp points at knot 0 of a row stored with its first knot repeated 3
 // times in front and its last knot 4 times behind (the reads g[s-3] .. g[s+4] need no index clamp; a repeated
 // knot only ever feeds a basis whose index is outside [0, C-1], which callers drop, and every denominator below
-// spans [g_s, g_{s+1}], so none is zero).  out.d3 is left zero.
-template <typename KnotPtr>
+// spans [g_s, g_{s+1}], so none is zero).  The interval is settled by exact comparisons, so with kNeedD3 the third
+// derivative (piecewise constant, jumping at the knots) is that of the reference's half-open interval; without it
+// out.d3 is left zero.
+template <bool kNeedD3 = false, typename KnotPtr>
 KAN_HD void eval_basis_near_uniform(const KnotPtr gp, int nk, float g0, float glast, float inv_h, float x, Basis& out) {
   const float u = (x - g0) * inv_h;
   int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
@@ -250,7 +252,15 @@ KAN_HD void eval_basis_near_uniform(const KnotPtr gp, int nk, float g0, float gl
   out.d2[1] = in ? 3.0f * (w_a - w_b) : 0.0f;
   out.d2[2] = in ? 3.0f * (w_b - w_c) : 0.0f;
   out.d2[3] = in ? 3.0f * w_c : 0.0f;
-  out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
+  if (kNeedD3) {
+    const float z_a = 2.0f * r1 * r2a * r3a, z_b = -2.0f * r1 * (r2a + r2b) * r3b, z_c = 2.0f * r1 * r2b * r3c;
+    out.d3[0] = in ? -3.0f * z_a : 0.0f;
+    out.d3[1] = in ? 3.0f * (z_a - z_b) : 0.0f;
+    out.d3[2] = in ? 3.0f * (z_b - z_c) : 0.0f;
+    out.d3[3] = in ? 3.0f * z_c : 0.0f;
+  } else {
+    out.d3[0] = out.d3[1] = out.d3[2] = out.d3[3] = 0.0f;
+  }
 }
 
 // 1/h when the nk knots are equally spaced to within 1e-6*h, else 0.  The default

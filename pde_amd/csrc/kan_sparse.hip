@@ -105,6 +105,17 @@ __device__ __forceinline__ void barrier_after_dma() {
   __syncthreads();
 }
 
+// Block-uniform: every feature's knot row is equally spaced or nearly so (ginfo != 0, see knot_spacing_info): the
+// condition under which the fp16 matrix kernels of kan_f16.hip run; the kernels here then leave the layer to them.
+__device__ __forceinline__ bool all_rows_near_uniform(const float* ginfo, int I) {
+  if (!ginfo) return false;
+  const int lane = threadIdx.x & 63;
+  bool near = true;
+  for (int i = lane; i < ((I + 63) & ~63); i += 64)
+    near = near && (__builtin_amdgcn_ballot_w64(ginfo[i < I ? i : 0] != 0.0f) == ~0ull);
+  return near;
+}
+
 // Basis and activation of one (point, feature) for the sparse kernels.
 struct Live {
   f32x4 b, d1, d2, d3;   // the 4 live bases and derivatives
@@ -214,7 +225,9 @@ template <int O, int FS, int RS = 64, bool MG = (RS != 64)>
 __global__ void __launch_bounds__(256, 2)
 fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                   const float* __restrict__ win,
-                  const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act, int OTr) {
+                  const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act, int OTr,
+                  int skip_near_uniform) {
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
   constexpr int OG = O / 32;              // output groups = lanes per point
   constexpr int PW = 64 / OG;             // points per wave
   constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
@@ -343,7 +356,8 @@ template <int O, int RS = 64, bool MG = (RS != 64)>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
                         const float* __restrict__ ginfo, const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
-                        int64_t N, int I, int G, int act, int OTr) {
+                        int64_t N, int I, int G, int act, int OTr, int skip_near_uniform) {
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
   constexpr int OG = O / 32;
   constexpr int PW = 64 / OG;
   constexpr int kMaxSlot = (RS == 64) ? kSlots - 1 : kRawRow - 4;
@@ -559,43 +573,47 @@ static void big_lds(Kern k, size_t bytes) {
 }
 
 template <int O, int FS, int RS = 64, bool MG = (RS != 64)>
-static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
+static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
+                              int skip) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));               // points per block
   auto k = fwd_sparse_kernel<O, FS, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, false, FS);
   big_lds(k, lds);
   const dim3 g((unsigned)((N + pts - 1) / pts), MG ? L.O / O : 1);
-  k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O);
+  k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip);
 }
 
-void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st) {
+void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
+                       bool skip_near_uniform) {
+  const int skip = skip_near_uniform ? 1 : 0;
   if (!window_layout(L)) {
-    fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st);
+    fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st, skip);
   } else if (L.O == 64) {
-    if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st);
-    else fwd_sparse_launch<64, 2>(L, a, win, y, N, st);
+    if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st, skip);
+    else fwd_sparse_launch<64, 2>(L, a, win, y, N, st, skip);
   } else {                                               // 128 outputs: two groups of 64 (faster than one lane group of 4 x 32)
-    fwd_sparse_launch<64, 4, 64, true>(L, a, win, y, N, st);
+    fwd_sparse_launch<64, 4, 64, true>(L, a, win, y, N, st, skip);
   }
 }
 
 template <int O, int RS = 64, bool MG = (RS != 64)>
 static void bwd_input_sparse_launch(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                                    int64_t N, hipStream_t st) {
+                                    int64_t N, hipStream_t st, int skip) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));
   auto k = bwd_input_sparse_kernel<O, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, true);
   big_lds(k, lds);
-  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O);
+  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O, skip);
 }
 
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                             int64_t N, hipStream_t st) {
-  if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st);
-  else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st);
-  else bwd_input_sparse_launch<64, 64, true>(L, a, gy, win, ga, N, st);
+                             int64_t N, hipStream_t st, bool skip_near_uniform) {
+  const int skip = skip_near_uniform ? 1 : 0;
+  if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st, skip);
+  else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st, skip);
+  else bwd_input_sparse_launch<64, 64, true>(L, a, gy, win, ga, N, st, skip);
 }
 
 }  // namespace pdekan

@@ -109,9 +109,27 @@ size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
          align_up(win_floats(D, D2, L) * 4) / 4 + align_up((size_t)L.I * 4) / 4;
 }
 
+// What the fp16 matrix kernels of a layer need beside the layer itself: its W planes, the per-jet maxima of its
+// input jets / of the cotangents of its outputs (4 words each, float bit patterns), the maximum of its packed
+// weights, and where to combine the maxima of what it produces (nullptr = nobody needs them).
+struct F16Io {
+  const float* wpl = nullptr;
+  const unsigned* act_in = nullptr;
+  const unsigned* cot_in = nullptr;
+  const unsigned* wmax = nullptr;
+  unsigned* act_out = nullptr;
+  unsigned* cot_out = nullptr;
+};
+
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
-                float* y, int64_t n, hipStream_t st, int li = 0) {
-  if (win && pdekan::sparse_eligible(D, D2, L)) {
+                float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr) {
+  if (h && h->wpl && win) {
+    // both on the same grid: the fp16 matrix kernel runs when every knot row is (nearly) equally spaced, else the
+    // sparse kernel does (decided on the device)
+    ProfScope ps(st, "L%d.fwd.mfma_f16x2", li);
+    pdekan::launch_fwd_f16(L, a, h->wpl, y, n, h->act_in, h->wmax, h->act_out, st);
+    pdekan::launch_fwd_sparse(L, a, win, y, n, st, true);
+  } else if (win && pdekan::sparse_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.sparse", li);
     pdekan::launch_fwd_sparse(L, a, win, y, n, st);
   } else if (pdekan::mfma_eligible(D, D2, L)) {
@@ -127,7 +145,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
 
 int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* gy, const float* wp,
                  const float* win, float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
-                 hipStream_t st, int li = 0) {
+                 hipStream_t st, int li = 0, const F16Io* h = nullptr) {
   const bool mf = pdekan::mfma_eligible(D, D2, L);
   if (g) {
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
@@ -152,7 +170,13 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
                                  L.scaler ? g->spline_scaler : nullptr, accumulate, st);
   }
   if (ga) {
-    if (win && pdekan::sparse_input_grad_eligible(D, D2, L)) {
+    if (h && h->wpl && win) {
+      // both on the same grid: the fp16 matrix kernel runs when every knot row is (nearly) equally spaced, else the
+      // sparse kernel does (decided on the device)
+      ProfScope ps(st, "L%d.bwd_input.mfma_f16x2", li);
+      pdekan::launch_bwd_input_f16(L, a, gy, h->wpl, ga, n, h->cot_in, h->wmax, h->cot_out, st);
+      pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st, true);
+    } else if (win && pdekan::sparse_input_grad_eligible(D, D2, L)) {
       ProfScope ps(st, "L%d.bwd_input.sparse", li);
       pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st);
     } else if (mf) {
@@ -255,8 +279,23 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
   return PDEKAN_OK;
 }
 
+// Maxima the fp16 matrix kernels scale their operands by, one 4-word slot each: per layer boundary l = 0 .. nl the
+// per-jet maxima of the jets entering layer l (act) and of the cotangents of those jets (cot), per layer the maximum of
+// its packed weights (w).  act and cot are cleared per micro-batch, w once per call.
+struct ModelStats {
+  unsigned* base; int nl;
+  static size_t words(int nl) { return (size_t)12 * (nl + 1); }
+  unsigned* act(int l) const { return base + 4 * l; }
+  unsigned* cot(int l) const { return base + 4 * (nl + 1) + 4 * l; }
+  unsigned* w(int l) const { return base + 8 * (nl + 1) + 4 * l; }
+  size_t per_batch_bytes() const { return (size_t)8 * (nl + 1) * 4; }
+  size_t bytes() const { return words(nl) * 4; }
+};
+
 struct ModelWs {
   std::vector<float*> wp, wt, win, ginfo, act;   // act[l] = input jets of layer l; act[n_layers] = output jets
+  std::vector<float*> wpl;                       // W planes of the layers the fp16 matrix kernels take, else nullptr
+  unsigned* stats;                               // maxima (float bit patterns), see ModelStats
   float* g[2];
   float* view[3];       // 4-jet views of a layer's input jets, cotangents and input gradients (split passes), else nullptr
   float* part;
@@ -276,7 +315,8 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     total += align_up(floats * 4);
     return ws ? c.take(floats) : nullptr;
   };
-  W.wp.resize(nl); W.wt.resize(nl); W.win.resize(nl); W.ginfo.resize(nl); W.act.resize(nl + 1);
+  W.wp.resize(nl); W.wt.resize(nl); W.win.resize(nl); W.ginfo.resize(nl); W.act.resize(nl + 1); W.wpl.resize(nl);
+  W.stats = reinterpret_cast<unsigned*>(take(ModelStats::words((int)nl)));
   for (size_t l = 0; l < nl; ++l) {
     W.wp[l] = take(P.L[l].packed_floats());
     W.wt[l] = take(P.L[l].packed_floats());
@@ -284,6 +324,8 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     const size_t wf = win_floats(P.D, P.D2, P.L[l]);
     W.win[l] = wf ? take(wf) : nullptr;
     if (!ws && wf) W.win[l] = reinterpret_cast<float*>(1);   // sizing pass: only the total matters
+    const bool f16 = wf && pdekan::f16_eligible(P.D, P.D2, P.L[l]);
+    W.wpl[l] = f16 ? take(pdekan::f16_wplane_floats(P.L[l])) : nullptr;
   }
   for (size_t l = 0; l <= nl; ++l) {
     const int w = (l < nl) ? P.L[l].I : P.L[nl - 1].O;
@@ -298,6 +340,43 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
   W.loss_part = take(kLossPartials);
   if (need) *need = total;
   return ws ? c.ok : true;
+}
+
+// Per call: knot-row classes, packed weights and the tables / planes derived from them, for every layer.
+int pack_model(ModelPlan& P, const ModelWs& W, const ModelStats& S, hipStream_t st) {
+  const int nl = (int)P.L.size();
+  hipError_t e = hipMemsetAsync(S.base, 0, S.bytes(), st);
+  if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "clearing the scale maxima: %s", hipGetErrorString(e));
+  for (int l = 0; l < nl; ++l) {
+    pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
+    P.L[l].ginfo = W.ginfo[l];
+    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
+    if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
+    if (W.wpl[l]) {
+      pdekan::launch_absmax(W.wp[l], (int64_t)P.L[l].packed_floats(), S.w(l), st);
+      pdekan::launch_pack_wplanes16(P.L[l], W.wp[l], S.w(l), W.wpl[l], st);
+    }
+  }
+  return check_launch("pack");
+}
+
+// Forward of layer l of a model on m points.  have_act: the per-jet maxima of the layer's input are already in
+// S.act(l) (the layer before was an fp16 matrix kernel too and left them there).
+int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& S, int l, float* dst, int64_t m,
+                        hipStream_t st, bool* act_ready) {
+  const int nl = (int)P.L.size();
+  F16Io io;
+  const bool f16 = W.wpl[l] != nullptr;
+  if (f16) {
+    if (!*act_ready) {
+      ProfScope ps(st, "L%d.jet_absmax", l);
+      pdekan::launch_jet_absmax(W.act[l], m * P.L[l].I, S.act(l), st);
+    }
+    io.wpl = W.wpl[l]; io.act_in = S.act(l); io.wmax = S.w(l);
+    io.act_out = (l + 1 < nl && W.wpl[l + 1]) ? S.act(l + 1) : nullptr;
+  }
+  *act_ready = f16 && io.act_out != nullptr;
+  return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr);
 }
 
 int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
@@ -444,19 +523,19 @@ int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const 
   if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
-  for (int l = 0; l < nl; ++l) {
-    pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
-    P.L[l].ginfo = W.ginfo[l];
-    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
-    if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
-  }
+  const ModelStats S = {W.stats, nl};
+  rc = pack_model(P, W, S, st);
+  if (rc) return rc;
   const int out_w = P.L[nl - 1].O;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
     const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
     pdekan::launch_seed_jets(P.D, P.D2, x + p0 * stride_n, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    if (p0 > 0 && hipMemsetAsync(S.base, 0, S.per_batch_bytes(), st) != hipSuccess)
+      return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
+    bool act_ready = false;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out_jet + p0 * out_w * P.J : W.act[l + 1];
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l);
+      rc = model_layer_forward(P, W, S, l, dst, m, st, &act_ready);
       if (rc) return rc;
     }
   }
@@ -481,14 +560,11 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
   const float inv_n = 1.0f / (float)n_global;
+  const ModelStats S = {W.stats, nl};
   {
     ProfScope ps(st, "pack_weights", 0);
-    for (int l = 0; l < nl; ++l) {
-      pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
-      P.L[l].ginfo = W.ginfo[l];
-      pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
-      if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
-    }
+    rc = pack_model(P, W, S, st);
+    if (rc) return rc;
   }
   bool first = true;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
@@ -501,8 +577,11 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     const pdekan::LayerView& H = P.L[nl - 1];
     const bool fused_head = pdekan::head_eligible(P.D, H) && !getenv_flag("PDEKAN_DISABLE_FUSED_HEAD");
     const int n_fwd = fused_head ? nl - 1 : nl;
+    if (p0 > 0 && hipMemsetAsync(S.base, 0, S.per_batch_bytes(), st) != hipSuccess)
+      return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
+    bool act_ready = false;
     for (int l = 0; l < n_fwd; ++l) {
-      rc = run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], W.act[l + 1], m, st, l);
+      rc = model_layer_forward(P, W, S, l, W.act[l + 1], m, st, &act_ready);
       if (rc) return rc;
     }
     const float* tgt = target ? target + p0 : nullptr;
@@ -538,6 +617,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
     }
     if (grads) {
+      bool cot_ready = false;
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
         if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
@@ -548,8 +628,21 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
             rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, nullptr, acc_flag,
                               m, st, l);
         } else {
+          F16Io io;
+          const bool f16 = W.wpl[l] != nullptr;
+          if (f16) {
+            // per-jet maxima of the cotangents of this layer's outputs: left by the layer above when it ran on the
+            // fp16 matrix kernels too, else measured here
+            if (!cot_ready) {
+              ProfScope ps(st, "L%d.jet_absmax", l);
+              pdekan::launch_jet_absmax(W.g[cur], m * P.L[l].O, S.cot(l + 1), st);
+            }
+            io.wpl = W.wpl[l]; io.act_in = S.act(l); io.cot_in = S.cot(l + 1); io.wmax = S.w(l);
+            io.cot_out = (gnext && l > 0 && W.wpl[l - 1]) ? S.cot(l) : nullptr;
+          }
+          cot_ready = f16 && io.cot_out != nullptr;
           rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, &grads[l], acc_flag,
-                            m, st, l);
+                            m, st, l, f16 ? &io : nullptr);
         }
         if (rc) return rc;
         cur ^= 1;

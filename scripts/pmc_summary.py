@@ -32,7 +32,7 @@ def main(dirs):
             for k in sorted(acc, key=lambda k: -sum(dur.get(k, [0]))):
                 if "pdekan" not in path and not acc[k]:
                     continue
-                if not any(s in k for s in ("mfma", "bf16x3", "head", "generic", "reduce", "sum_partials", "sparse", "pack")):
+                if not any(s in k for s in ("mfma", "bf16x3", "f16", "head", "generic", "reduce", "sum_partials", "sparse", "pack", "absmax")):
                     continue
                 n = len(next(iter(acc[k].values())))
                 ms = (sum(dur[k]) / len(dur[k]) / 1e6) if dur.get(k) else float("nan")

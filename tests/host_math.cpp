@@ -126,13 +126,13 @@ float hm_equal_spacing_inv_h(const float* knots, int nk) { return equal_spacing_
 
 float hm_knot_spacing_info(const float* knots, int nk) { return knot_spacing_info(knots, nk); }
 
-// the general-knot evaluation of the split-bf16 weight-gradient kernel, on a row padded the way the kernel stages it
+// the general-knot evaluation of the matrix-core kernels (with the third derivative), on a row padded the way they stage it
 void hm_eval_basis_near_uniform(const float* knots, int nk, float x, float* out16, int* c0, int* inside) {
   std::vector<float> row;
   for (int k = -3; k < nk + 4; ++k) row.push_back(knots[k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k)]);
   const float h = (knots[nk - 1] - knots[0]) / (float)(nk - 1);
   Basis bs;
-  eval_basis_near_uniform(row.data() + 3, nk, knots[0], knots[nk - 1], 1.0f / h, x, bs);
+  eval_basis_near_uniform<true>(row.data() + 3, nk, knots[0], knots[nk - 1], 1.0f / h, x, bs);
   for (int m = 0; m < 4; ++m) { out16[m] = bs.b[m]; out16[4 + m] = bs.d1[m]; out16[8 + m] = bs.d2[m]; out16[12 + m] = bs.d3[m]; }
   *c0 = bs.c0; *inside = bs.inside;
 }

@@ -187,8 +187,9 @@ def test_knot_spacing_classes(hm):
 @pytest.mark.parametrize("kind", ["default20", "default10", "jittered"])
 def test_near_uniform_path_matches_dense_cox_de_boor(hm, kind):
     """eval_basis_near_uniform (8 knots around the quotient guess, interval settled in registers, general triangle)
-    against dense Cox-de Boor in fp64 on the same fp32 knots: B, B', B'' everywhere, knots and their fp32
-    neighbours included, and the reference's half-open interval convention."""
+    against dense Cox-de Boor in fp64 on the same fp32 knots: B and its first three derivatives everywhere, knots and
+    their fp32 neighbours included, and the reference's half-open interval convention (the third derivative jumps at
+    the knots: the interval must be the exact one)."""
     G = 20 if kind == "default20" else 10
     knots = O.uniform_grid(1, G)[0].numpy().copy()
     h = 2.0 / G
@@ -200,9 +201,9 @@ def test_near_uniform_path_matches_dense_cox_de_boor(hm, kind):
     around = np.concatenate([np.nextafter(knots, -np.inf), knots, np.nextafter(knots, np.inf)])
     xs = np.concatenate([np.linspace(-1.0 - 3 * h - 0.05, 1.0 + 3 * h + 0.05, 3001), around,
                          [-7.0, 9.0, 1e30, -1e30, np.inf, -np.inf, np.nan]]).astype(np.float32)
-    ref = dense_reference(knots, xs, C, orders=3)
+    ref = dense_reference(knots, xs, C, orders=4)
     hmin = np.diff(knots.astype(np.float64)).min()
-    scale = np.array([1.0, 1 / hmin, 1 / hmin ** 2])[:, None]
+    scale = np.array([1.0, 1 / hmin, 1 / hmin ** 2, 1 / hmin ** 3])[:, None]
     b = np.zeros(16, np.float32)
     cb, ib = ctypes.c_int(), ctypes.c_int()
     worst = 0.0
@@ -215,11 +216,11 @@ def test_near_uniform_path_matches_dense_cox_de_boor(hm, kind):
             continue
         s = cb.value + 3
         assert knots[s] <= x < knots[s + 1]
-        dense = np.zeros((3, C))
+        dense = np.zeros((4, C))
         for m in range(4):
             if 0 <= cb.value + m < C:
-                dense[:, cb.value + m] = b[m:12:4]
-        worst = max(worst, np.abs((dense - ref[:3, n]) / scale).max())
+                dense[:, cb.value + m] = b[m:16:4]
+        worst = max(worst, np.abs((dense - ref[:4, n]) / scale).max())
     assert worst < (4e-6 if kind != "jittered" else 1.5e-5), worst
 
 
