@@ -393,8 +393,16 @@ struct FwdF16 {
   }
 };
 
-template <int C1, int ACT, bool GEN>
-__global__ void __launch_bounds__(256, 2)
+// LONGK: layers with many input features.  The matrix instructions' accumulate is not round-to-nearest: a sum kept
+// in their accumulators drifts with the number of instructions chained on it (measured on a 256-input grid-20
+// layer, 576 in a row: 1.5e-5 of the result).  LONGK moves the running sums into a second set of registers with
+// vector adds every kFwdFlushStages stages (one wave per SIMD: 64 more registers); narrower layers chain at most
+// 128 instructions and keep two waves per SIMD.
+constexpr int kFwdFlushStages = 8;
+constexpr int kFwdChainMax = 128;            // matrix instructions chained on one accumulator without LONGK
+
+template <int C1, int ACT, bool GEN, bool LONGK>
+__global__ void __launch_bounds__(256, LONGK ? 1 : 2)
 fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
                const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
@@ -480,6 +488,13 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
     }
     ATile16 cur = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 0);
     ATile16 nxt = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 1);
+    f32x4 tot[LONGK ? 4 : 1][LONGK ? 4 : 1];
+    if constexpr (LONGK) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) tot[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int s = 0; s < nst; s += 2) {
       // stages past the end: any valid data, expanded and parked but never multiplied
       const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : 0, s3 = (s + 3 < nst) ? s + 3 : 0;
@@ -489,6 +504,20 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
       F::template stage<(KS & 1) != 0>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s2 * KP, sc, prev_c0,
                                        wbase + (size_t)s1 * F::kStageVecs, wbase + (size_t)s2 * F::kStageVecs,
                                        xrow + (size_t)s3 * 64, aoff, lane);
+      if constexpr (LONGK) {
+        if (((s + 2) % kFwdFlushStages) == 0) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { tot[m][n] += acc[m][n]; acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+      }
+    }
+    if constexpr (LONGK) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] += tot[m][n];
     }
     // D[(p, j)][output]: this lane holds the 4 jets of point 4m + kb for output 16n + r
     f32x4 inv;
@@ -754,6 +783,273 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
 }
 
 // ==========================================================================================================
+// weight gradients.  gW[k][o] = sum over (p, j) of E[(p, j)][k] * gY[(p, j)][o]: M = 16 columns, N = 16 outputs,
+// K = 32 = 8 points x 4 jets.  Every wave is on its own (no block barrier): wave = FE features x C1 columns
+// (NT = FE*C1/16 column tiles: 8 x 14 at grid 10, 4 x 24 at grid 20) x 64 outputs of accumulators over a chunk of
+// points, walked 8 points at a time.  One wave per SIMD (224 accumulator registers), so the instruction stream is
+// software-pipelined in source: the vector work that prepares step s+1 sits between the matrix instructions of
+// step s, one fenced region of 12 matrix instructions per column tile.
+//   B operand (gY): lane (r = lane&15, q = lane>>4) holds output 16m + r, jets of points 2q and 2q+1: two 16-byte
+//     loads per output tile, fetched two steps ahead, scaled per jet and cut into planes at the start of their step.
+//   A operand (E^T): lane (p = lane&7, f = lane>>3) expands its (point, feature) pair, cuts the 20 scaled jets and
+//     parks them in the wave's own LDS tile [2 planes][FE*C1 columns][32 fp16 + pad]; the 4 columns it wrote one
+//     step earlier are cleared, everything else of the tile stays zero.  Read back in operand order (ds_read_b128).
+// The jet index is summed over here, so the scales of the two operands are tied: gY's jet j by t_j (its own
+// maximum under 2^13), E's by s_j = c / t_j with the one power of two c that keeps every s_j * max|E_j| under 2^13.
+// The matrix instructions' accumulate is not round-to-nearest: they run 512 points at a time into acc, which is
+// then added (vector add) into tot and cleared.
+// Blocks (4 waves = 4*FE features) run in the variant that matches their features' knot rows (GEN = false: all
+// equally spaced; GEN = true: all at least nearly so); bwd_weight_mfma_kernel with skip_uniform = 1, launched on the
+// same grid, does the blocks both leave out.  Output: part[chunk][O][I][C1].
+// ==========================================================================================================
+constexpr int kF16FlushPoints = 512;
+constexpr int kWgRw = 20;                    // words per E tile row: 32 fp16 + 16 bytes of pad (bank spread; dump slot)
+
+struct GyPlanes16 { u32x4 h[4], l[4]; };     // 4 output tiles x (2 points x 4 jets)
+struct TileOps16 { u32x4 h, l; };
+
+__device__ __forceinline__ void split_gy_tile16(const f32x4 (&g)[2], const f32x4& t, GyPlanes16& G, int m) {
+  const Planes16 p0 = split_jet16(g[0] * t), p1 = split_jet16(g[1] * t);
+  G.h[m] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
+  G.l[m] = (u32x4){p0.l.x, p0.l.y, p1.l.x, p1.l.y};
+}
+
+template <int C1, int COLS>
+__device__ __forceinline__ void park_wg16(unsigned* base, unsigned* dump, const Planes16 (&pp)[5], int c0, int& prev_c0) {
+  constexpr int C = C1 - 1, PL = COLS * kWgRw;
+  const u32x2 zero = {0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = prev_c0 + m;
+    unsigned* dst = (c >= 0 && c < C) ? base + c * kWgRw : dump;
+    *reinterpret_cast<u32x2*>(dst) = zero;
+    *reinterpret_cast<u32x2*>(dst + PL) = zero;
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = (m < 4) ? c0 + m : C;
+    unsigned* dst = (m == 4 || (c >= 0 && c < C)) ? base + c * kWgRw : dump;
+    *reinterpret_cast<u32x2*>(dst) = pp[m].h;
+    *reinterpret_cast<u32x2*>(dst + PL) = pp[m].l;
+  }
+  prev_c0 = c0;
+}
+
+template <int COLS>
+__device__ __forceinline__ TileOps16 read_wg_tile(const unsigned* esrc, int t) {
+  TileOps16 o;
+  o.h = *reinterpret_cast<const u32x4*>(esrc + t * 16 * kWgRw);
+  o.l = *reinterpret_cast<const u32x4*>(esrc + t * 16 * kWgRw + COLS * kWgRw);
+  return o;
+}
+
+__device__ __forceinline__ void mfma_wg_tile(f32x4 (&acc)[4], const TileOps16& e, const GyPlanes16& G) {
+  const f16x8 eh = __builtin_bit_cast(f16x8, e.h), el = __builtin_bit_cast(f16x8, e.l);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, __builtin_bit_cast(f16x8, G.h[m]), acc[m], 0, 0, 0);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(f16x8, G.l[m]), acc[m], 0, 0, 0);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(f16x8, G.h[m]), acc[m], 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 ld16v(const char* __restrict__ row, unsigned off) {
+  return *reinterpret_cast<const f32x4*>(row + off);
+}
+
+// One step = 8 points = NT regions of 12 matrix instructions (one column tile each).  graw / xraw hold the raw rows
+// of step s+1 on entry; each piece is fetched again (rows of step s+2) right after the region that consumed it:
+//   region 0          evaluate and scale the pairs of step s+1 (xraw); fetch gY tile 3 of step s+1
+//   region 1          fetch xraw of step s+2; cut the pairs' columns 0, 1, 2
+//   region 2          cut columns 3, 4
+//   regions NT-4 ..   scale and cut gY tile 0..3 of step s+1 (Gn); regions NT-3 .. fetch tiles 0..2 of step s+2
+//   region NT-3       read the operands of the last tile, then park the pairs' planes of step s+1
+//   region NT-1       read the first operands of step s+1
+template <int C1, int FE, int ACT, bool GEN>
+__device__ __forceinline__ void wg16_step(f32x4 (&acc)[FE * C1 / 16][4], const GyPlanes16& G, GyPlanes16& Gn, TileOps16& cur,
+                                          f32x4 (&graw)[4][2], f32x4& xraw, unsigned* sE, const float* knots,
+                                          const FeatGrid& fg, const JetScales& se, const f32x4& tg, int& prev_c0,
+                                          const char* __restrict__ xrow2, const char* __restrict__ grow1,
+                                          const char* __restrict__ grow2, unsigned xoff, unsigned goff, int lane, int O) {
+  constexpr int COLS = FE * C1, NT = COLS / 16, nk = C1 + 3;
+  static_assert(NT == 6 || NT == 7, "the region plan below is written for 6 or 7 column tiles");
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
+  const unsigned* esrc = sE + r * kWgRw + q * 4;
+  PairCols pj;
+  Planes16 pp[5];
+  TileOps16 last;                             // operands of the last tile, read one region early so that the park can go early
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    TileOps16 nxt;
+    if (t + 1 < NT - 1) nxt = read_wg_tile<COLS>(esrc, t + 1);
+    if (t == NT - 3) last = read_wg_tile<COLS>(esrc, NT - 1);
+    if (t == NT - 2) nxt = last;
+    if (t == 0) {
+      expand_scaled<ACT, GEN>(knots, nk, fg, xraw, se, pj);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) graw[3][e] = ld16v(grow1, goff + (unsigned)(e * O + 3 * 16) * 16u);
+    }
+    if (t == 1) {
+      xraw = ld16v(xrow2, xoff);
+      pp[0] = split_jet16(pj.col[0]); pp[1] = split_jet16(pj.col[1]); pp[2] = split_jet16(pj.col[2]);
+    }
+    if (t == 2) { pp[3] = split_jet16(pj.col[3]); pp[4] = split_jet16(pj.col[4]); }
+    if (t >= NT - 4) split_gy_tile16(graw[t - (NT - 4)], tg, Gn, t - (NT - 4));
+    if (t >= NT - 3) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        graw[t - (NT - 3)][e] = ld16v(grow2, goff + (unsigned)(e * O + (t - (NT - 3)) * 16) * 16u);
+    }
+    if (t == NT - 3) {                        // every operand read of this step's E tile has been issued
+      unsigned* base = sE + (f_local * C1) * kWgRw + p_local * 2;
+      park_wg16<C1, COLS>(base, sE + (f_local * C1) * kWgRw + 16, pp, pj.c0, prev_c0);
+    }
+    if (t == NT - 1) nxt = read_wg_tile<COLS>(esrc, 0);
+    mfma_wg_tile(acc[t], cur, G);
+    cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int C1, int FE, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                      const float* __restrict__ ginfo, float* __restrict__ part, int64_t N, int I, int O,
+                      int64_t chunk_pts, int nx, int ny, int nz, const unsigned* __restrict__ act_in,
+                      const unsigned* __restrict__ cot_in) {
+  constexpr int COLS = FE * C1, NT = COLS / 16, nk = C1 + 3;
+  static_assert(COLS % 16 == 0 && (FE == 8 || FE == 4), "16-wide column tiles; 8 points x FE features per step");
+  constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  constexpr int kWaveWords = 2 * COLS * kWgRw + FE * KP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bx, by, bz;                             // blocks that read the same gY rows are 8 ids apart: one XCD's L2
+  {
+    const int b = blockIdx.x;
+    if (nz % 8 == 0) {
+      const int rr = b >> 3;
+      bx = rr % nx; by = (rr / nx) % ny; bz = (rr / (nx * ny)) * 8 + (b & 7);
+    } else {
+      bx = b % nx; by = (b / nx) % ny; bz = b / (nx * ny);
+    }
+  }
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  {                                           // the block's features: all equally spaced -> GEN = false takes it;
+    const float gi = ginfo[bx * 4 * FE + lane % (4 * FE)];          // all at least nearly so -> GEN = true
+    const bool all_near = __builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull;
+    const bool all_equal = __builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull;
+    if (!all_near || all_equal == GEN) return;
+  }
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;     // this wave's tile: [2][COLS][kWgRw]
+  float* sK = reinterpret_cast<float*>(sE + 2 * COLS * kWgRw);              // and its FE knot rows
+  // FE = 4: lanes 32..63 repeat the pairs of lanes 0..31 (same values to the same LDS words)
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
+  const int i0 = (bx * 4 + wave) * FE, o0 = by * 64;
+  if constexpr (GEN) {                        // [g_0 x3][the nk knots][g_last x4]
+    for (int idx = lane; idx < FE * KP; idx += 64) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = grid[(size_t)(i0 + f) * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = lane; idx < FE * (nk + 1); idx += 64) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)(i0 + f) * nk + k] : ginfo[i0 + f];
+    }
+  }
+  for (int idx = lane; idx < 2 * COLS * kWgRw; idx += 64) sE[idx] = 0u;
+  const float* knots = sK + f_local * KP + (GEN ? 3 : 0);
+  const FeatGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
+                       fabsf(ginfo[i0 + f_local])};
+  // scales: gY's jet j by t_j; E's jet j by c / t_j, c = the smallest of (scale that E_j alone could take) * t_j
+  JetScales se;
+  f32x4 tg;
+  float inv_c;
+  {
+    const JetScales eb = expanded_jet_scales(act_in, max_inv_h(ginfo, I, lane));
+    float c = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tg[j] = pow2_scale(__uint_as_float(cot_in[j]));
+      c = fminf(c, eb.s[j] * tg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) se.s[j] = c * rcp_pow2(tg[j]);
+    inv_c = rcp_pow2(c);
+  }
+
+  f32x4 acc[NT][4], tot[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  // N and chunk_pts are multiples of 16: whole pairs of steps
+  const int64_t pbeg = (int64_t)bz * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  const char* xb = reinterpret_cast<const char*>(a);
+  const char* gb = reinterpret_cast<const char*>(gy);
+  const unsigned xoff = (unsigned)(p_local * I + i0 + f_local) * 16u;
+  const unsigned goff = (unsigned)(2 * q * O + o0 + r) * 16u;
+  const size_t xstride = (size_t)I * 16, gstride = (size_t)O * 16;       // bytes per point
+
+  if (pbeg < pend) {
+    f32x4 graw[4][2], xraw;
+    GyPlanes16 GA, GB;
+    int prev_c0 = -100;
+    {
+      f32x4 g0[4][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          g0[m][e] = ld16v(gb + pbeg * gstride, goff + (unsigned)(e * O + m * 16) * 16u);
+          graw[m][e] = ld16v(gb + (pbeg + 8) * gstride, goff + (unsigned)(e * O + m * 16) * 16u);
+        }
+      const f32x4 x0 = ld16v(xb + pbeg * xstride, xoff);
+      xraw = ld16v(xb + (pbeg + 8) * xstride, xoff);
+      PairCols pj;
+      Planes16 pp[5];
+      expand_scaled<ACT, GEN>(knots, nk, fg, x0, se, pj);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) pp[m] = split_jet16(pj.col[m]);
+      unsigned* base = sE + (f_local * C1) * kWgRw + p_local * 2;
+      park_wg16<C1, COLS>(base, sE + (f_local * C1) * kWgRw + 16, pp, pj.c0, prev_c0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) split_gy_tile16(g0[m], tg, GA, m);
+    }
+    TileOps16 cur = read_wg_tile<COLS>(sE + r * kWgRw + q * 4, 0);
+    for (int64_t pb = pbeg; pb < pend;) {
+      const int64_t pstop = (pb + kF16FlushPoints < pend) ? pb + kF16FlushPoints : pend;
+      for (; pb < pstop; pb += 16) {
+        // past the end of the chunk: any valid rows, fetched (and expanded) but never used
+        const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
+        wg16_step<C1, FE, ACT, GEN>(acc, GA, GB, cur, graw, xraw, sE, knots, fg, se, tg, prev_c0, xb + p2 * xstride,
+                                    gb + p1 * gstride, gb + p2 * gstride, xoff, goff, lane, O);
+        wg16_step<C1, FE, ACT, GEN>(acc, GB, GA, cur, graw, xraw, sE, knots, fg, se, tg, prev_c0, xb + p3 * xstride,
+                                    gb + p2 * gstride, gb + p3 * gstride, xoff, goff, lane, O);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          tot[t][m] += acc[t][m];
+          acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+  // D[row][output]: this lane holds columns 16t + 4q .. + 3 of output 16m + r
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float* dst = part + (((size_t)bz * O + o0 + m * 16 + r) * I + i0) * C1 + t * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(dst) = tot[t][m] * inv_c;
+    }
+}
+
+// ==========================================================================================================
 // host side
 // ==========================================================================================================
 static bool f16_disabled() {
@@ -811,7 +1107,8 @@ template <int C1, int ACT, bool GEN>
 static void fwd_f16_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
                            const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
   using F = FwdF16<C1, ACT, GEN>;
-  auto k = fwd_f16_kernel<C1, ACT, GEN>;
+  const bool longk = (L.I / 4) * F::KS * 3 > kFwdChainMax;
+  auto k = longk ? fwd_f16_kernel<C1, ACT, GEN, true> : fwd_f16_kernel<C1, ACT, GEN, false>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * 2 * F::PLANE) * 4;
   allow_lds(k, lds);
   dim3 g((unsigned)((N + 63) / 64), L.O / 64);
@@ -868,6 +1165,35 @@ void launch_bwd_input_f16(const LayerView& L, const float* a, const float* gy, c
   const float* wplb = wpl + f16_wplane_floats(L) / 2;
   if (L.G == 10) bwi_f16_variants<14>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
   else bwi_f16_variants<24>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+}
+
+template <int C1, int FE>
+static void bww_f16_launch(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16, int64_t chunk,
+                           int nx, int ny, int nmain, const unsigned* act_in, const unsigned* cot_in, hipStream_t st) {
+  auto kb = (L.act == kActSiLU) ? bwd_weight_f16_kernel<C1, FE, kActSiLU, false>
+                                : bwd_weight_f16_kernel<C1, FE, kActIdentity, false>;
+  auto kg = (L.act == kActSiLU) ? bwd_weight_f16_kernel<C1, FE, kActSiLU, true>
+                                : bwd_weight_f16_kernel<C1, FE, kActIdentity, true>;
+  const size_t lds_b = (size_t)4 * (2 * FE * C1 * kWgRw + FE * kKnotPadU) * 4;
+  const size_t lds_g = (size_t)4 * (2 * FE * C1 * kWgRw + FE * kKnotPadN) * 4;
+  allow_lds(kb, lds_b);
+  allow_lds(kg, lds_g);
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
+  kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
+}
+
+// The two variants on the grid of bwd_weight_mfma_kernel (blocks of 4*FE features x 64 outputs x nmain chunks of
+// `chunk` points, N16 and chunk multiples of 16): a block runs in the variant that matches its features' knot rows.
+// act_in / cot_in: per-jet maxima of a and gy (4 words each).
+void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16,
+                                  int64_t chunk, int nx, int ny, int nmain, const unsigned* act_in,
+                                  const unsigned* cot_in, hipStream_t st) {
+  if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
+  else bww_f16_launch<24, 4>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
 }
 
 }  // namespace pdekan

@@ -91,7 +91,12 @@ void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, 
                            int64_t N, hipStream_t st);
 // with_bf16x3: feature blocks with equally spaced knots go to the split-bf16 kernel, the rest stay fp32
 bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N);
+// act_in / cot_in (per-jet maxima of a and gy, 4 words each) given: the fp16 two-piece kernel instead of the split-bf16 one
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
-                            int64_t N, hipStream_t st, bool with_bf16x3 = false);
+                            int64_t N, hipStream_t st, bool with_bf16x3 = false, const unsigned* act_in = nullptr,
+                            const unsigned* cot_in = nullptr);
+void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16,
+                                  int64_t chunk, int nx, int ny, int nmain, const unsigned* act_in,
+                                  const unsigned* cot_in, hipStream_t st);
 
 }  // namespace pdekan

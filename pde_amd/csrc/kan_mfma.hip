@@ -1078,7 +1078,8 @@ bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N) {
 
 template <int C1, int KIW, int PB>
 static void bww_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
-                       hipStream_t st, bool with_bf16x3 = false) {
+                       hipStream_t st, bool with_bf16x3 = false, const unsigned* act_in = nullptr,
+                       const unsigned* cot_in = nullptr) {
   constexpr int COLS = KIW * C1, ROWS = PB * 4, RS = ROWS + 4;
   const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
@@ -1101,6 +1102,9 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
     chunk = (chunk + 15) / 16 * 16;
     k<<<(unsigned)(nx * ny * nmain), 256, lds, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, L.act, chunk, nx, ny,
                                                      nmain, 1);
+    if (act_in && cot_in) {                              // fp16 two-piece kernels, same block decode and selection
+      launch_bwd_weight_f16_blocks(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
+    } else {
     // both variants on the same grid: a block runs in the one that matches its features' knot rows
     auto kb = (L.act == kActSiLU) ? bwd_weight_bf16x3_kernel<C1, KIW, kActSiLU, false>
                                   : bwd_weight_bf16x3_kernel<C1, KIW, kActIdentity, false>;
@@ -1112,6 +1116,7 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
     allow_big_lds(kg, lds_g);
     kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain);
     kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain);
+    }
     if (tail)                                            // the last chunk slot: the points past N16, fp32 kernel, all blocks
       k<<<(unsigned)(nx * ny), 256, lds, st>>>(a4 + (size_t)N16 * L.I, g4 + (size_t)N16 * L.O, L.grid, L.ginfo,
                                                part + (size_t)nmain * L.packed_floats(), tail, L.I, L.O, L.act, 16, nx, ny,
@@ -1120,9 +1125,9 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
 }
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
-                            hipStream_t st, bool with_bf16x3) {
-  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3);
-  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3);
+                            hipStream_t st, bool with_bf16x3, const unsigned* act_in, const unsigned* cot_in) {
+  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in);
+  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in);
   else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
 }
 

@@ -151,7 +151,10 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
       return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
     const int nch = weight_chunks(D, D2, L, n);
-    if (mf && pdekan::bf16x3_weight_eligible(D, D2, L, n)) {
+    if (mf && pdekan::bf16x3_weight_eligible(D, D2, L, n) && h && h->wpl && h->act_in && h->cot_in) {
+      ProfScope ps(st, "L%d.bwd_weight.mfma_f16x2", li);
+      pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st, true, h->act_in, h->cot_in);
+    } else if (mf && pdekan::bf16x3_weight_eligible(D, D2, L, n)) {
       ProfScope ps(st, "L%d.bwd_weight.mfma_bf16x3", li);
       pdekan::launch_bwd_weight_mfma(L, a, gy, part, nch, n, st, true);
     } else if (mf) {
