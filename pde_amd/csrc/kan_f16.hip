@@ -85,7 +85,15 @@ __device__ __forceinline__ float max_inv_h(const float* ginfo, int I, int lane) 
 // out[j] = max(out[j], bits of max |t[e][j]|) over e < n4: per-jet maxima of a jet tensor laid out [...][4]
 __global__ void jet_absmax_kernel(const f32x4* __restrict__ t, int64_t n4, unsigned* __restrict__ out) {
   f32x4 m = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e + 3 * stride < n4; e += 4 * stride) {           // 4 loads in flight per thread
+    const f32x4 v0 = t[e], v1 = t[e + stride], v2 = t[e + 2 * stride], v3 = t[e + 3 * stride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      m[j] = fmaxf(fmaxf(m[j], fmaxf(fabsf(v0[j]), fabsf(v1[j]))), fmaxf(fabsf(v2[j]), fabsf(v3[j])));
+  }
+  for (; e < n4; e += stride) {
     const f32x4 v = t[e];
 #pragma unroll
     for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[j]));
@@ -118,9 +126,12 @@ __device__ __forceinline__ void publish_jet_max(f32x4 m, unsigned* out, int lane
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], d));
   }
-  if (lane == 0) {
+  if (lane == 0) {                              // look before queueing on the four shared words: see publish_jet_absmax
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicMax(out + j, __float_as_uint(m[j]));
+    for (int j = 0; j < 4; ++j) {
+      const unsigned mine = __float_as_uint(m[j]);
+      if (mine > __hip_atomic_load(out + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + j, mine);
+    }
   }
 }
 

@@ -26,7 +26,8 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
                const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ ginfo,
                const float* __restrict__ wp,
                float sigma, float rate, float inv_n, float* __restrict__ res_out, float* __restrict__ ga,
-               float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G, int act) {
+               float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G, int act,
+               unsigned* __restrict__ cot_out) {
   constexpr int J = 1 + D + D2;
   static_assert(D2 == D - 1, "assets first, time last");
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
@@ -50,6 +51,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   float* acc = s_acc + wave * I * C1;
   const float hs2 = 0.5f * sigma * sigma;
   float loss_local = 0.0f;
+  float gmax[4] = {0.f, 0.f, 0.f, 0.f};                   // J = 4: per-jet maxima of the cotangents written to ga
 
   // A wave works on one point at a time, so the loads of the NEXT point (its jets, coordinates and
   // target) are issued before the current point's arithmetic: their HBM latency hides behind it.
@@ -140,21 +142,29 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
           }
           if (ga) {
             float* dst = ga + (p * I + i) * J;
-            dst[0] = A0 * ph1[f] + A1 * ph2[f] + A2 * ph3[f];
+            float out[J];
+            out[0] = A0 * ph1[f] + A1 * ph2[f] + A2 * ph3[f];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
               float v = gy[1 + d] * ph1[f];
               if (d < D2) v += 2.0f * jet[f][1 + d] * gy[1 + D + d] * ph2[f];
-              dst[1 + d] = v;
+              out[1 + d] = v;
             }
 #pragma unroll
-            for (int d = 0; d < D2; ++d) dst[1 + D + d] = gy[1 + D + d] * ph1[f];
+            for (int d = 0; d < D2; ++d) out[1 + D + d] = gy[1 + D + d] * ph1[f];
+#pragma unroll
+            for (int j = 0; j < J; ++j) dst[j] = out[j];
+            if constexpr (J == 4) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) gmax[j] = fmaxf(gmax[j], fabsf(out[j]));
+            }
           }
         }
       }
     }
   }
 #undef PDEKAN_HEAD_FETCH
+  if (J == 4 && cot_out && ga) publish_jet_absmax(gmax[0], gmax[1], gmax[2], gmax[3], cot_out);
   if (lane == 0) s_loss[wave] = loss_local;
   __syncthreads();
   if (part) {
@@ -204,30 +214,30 @@ int head_blocks(int64_t N, const LayerView& L) {
 template <int D, int D2, int NF>
 static void head_launch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                         const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
-                        float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
+                        float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
   const int nw = head_waves(L);
   const size_t lds = head_lds_bytes(L);
   auto k = head_bs_kernel<D, D2, NF>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, L.ginfo, wp, sigma, rate, inv_n, res, ga, part, loss_part,
-                                   N, L.I, L.G, L.act);
+                                   N, L.I, L.G, L.act, cot_out);
 }
 
 template <int D, int D2>
 static void head_dispatch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                           const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
-                          float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
-  if (L.I <= 64) head_launch<D, D2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
-  else if (L.I <= 128) head_launch<D, D2, 2>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
-  else head_launch<D, D2, 4>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+                          float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
+  if (L.I <= 64) head_launch<D, D2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else if (L.I <= 128) head_launch<D, D2, 2>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else head_launch<D, D2, 4>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
 }
 
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
-                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st) {
-  if (D == 2) head_dispatch<2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
-  else head_dispatch<6, 5>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st);
+                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
+  if (D == 2) head_dispatch<2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else head_dispatch<6, 5>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
 }
 
 }  // namespace pdekan

@@ -51,7 +51,8 @@ bool head_eligible(int D, const LayerView& L);
 int head_blocks(int64_t N, const LayerView& L);
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t stride_n, int64_t stride_d,
                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
-                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st);
+                    float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st,
+                    unsigned* cot_out = nullptr);   // 4-jet models: per-jet maxima of ga are combined into cot_out
 
 // kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
 bool sparse_eligible(int D, int D2, const LayerView& L);
@@ -60,8 +61,9 @@ size_t sparse_table_floats(const LayerView& L);
 void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStream_t st);
 // skip_near_uniform: return at once when every knot row is (nearly) equally spaced - the fp16 matrix kernel launched
 // beside this one does the layer then
+// amax_out: where the per-jet maxima of y are combined into (4 words, see kan_f16.hip), or nullptr
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
-                       bool skip_near_uniform = false);
+                       bool skip_near_uniform = false, unsigned* amax_out = nullptr);
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
                              int64_t N, hipStream_t st, bool skip_near_uniform = false);
 

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 2)
 fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                   const float* __restrict__ win,
                   const float* __restrict__ wbt, float* __restrict__ y, int64_t N, int I, int G, int act, int OTr,
-                  int skip_near_uniform) {
+                  int skip_near_uniform, unsigned* __restrict__ amax_out) {
   if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
   constexpr int OG = O / 32;              // output groups = lanes per point
   constexpr int PW = 64 / OG;             // points per wave
@@ -322,6 +322,17 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
       L = eval_live<false, kMaxSlot>(sK + n * kKnotPadS, nk, act, cur[0]);
       barrier_after_dma();                 // table i+1 landed everywhere; table i no longer read
     }
+  }
+  if (amax_out) {                          // per-jet maxima of the outputs, for the scales of an fp16 matrix layer above
+    f32x2 ml = {0.f, 0.f}, mh = {0.f, 0.f};
+    if (live_pt) {
+#pragma unroll
+      for (int o = 0; o < 32; ++o) {
+        ml[0] = fmaxf(ml[0], fabsf(accl[o][0])); ml[1] = fmaxf(ml[1], fabsf(accl[o][1]));
+        mh[0] = fmaxf(mh[0], fabsf(acch[o][0])); mh[1] = fmaxf(mh[1], fabsf(acch[o][1]));
+      }
+    }
+    publish_jet_absmax(ml[0], ml[1], mh[0], mh[1], amax_out);
   }
   // Epilogue: a lane holds 32 outputs x 4 jets of one point (512 contiguous bytes in y).  Stored
   // straight from registers every instruction would touch 64 different lines 16 bytes at a time, so the
@@ -574,26 +585,26 @@ static void big_lds(Kern k, size_t bytes) {
 
 template <int O, int FS, int RS = 64, bool MG = (RS != 64)>
 static void fwd_sparse_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
-                              int skip) {
+                              int skip, unsigned* amax_out) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));               // points per block
   auto k = fwd_sparse_kernel<O, FS, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, false, FS);
   big_lds(k, lds);
   const dim3 g((unsigned)((N + pts - 1) / pts), MG ? L.O / O : 1);
-  k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip);
+  k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip, amax_out);
 }
 
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
-                       bool skip_near_uniform) {
+                       bool skip_near_uniform, unsigned* amax_out) {
   const int skip = skip_near_uniform ? 1 : 0;
   if (!window_layout(L)) {
-    fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st, skip);
+    fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st, skip, amax_out);
   } else if (L.O == 64) {
-    if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st, skip);
-    else fwd_sparse_launch<64, 2>(L, a, win, y, N, st, skip);
+    if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st, skip, amax_out);
+    else fwd_sparse_launch<64, 2>(L, a, win, y, N, st, skip, amax_out);
   } else {                                               // 128 outputs: two groups of 64 (faster than one lane group of 4 x 32)
-    fwd_sparse_launch<64, 4, 64, true>(L, a, win, y, N, st, skip);
+    fwd_sparse_launch<64, 4, 64, true>(L, a, win, y, N, st, skip, amax_out);
   }
 }
 

@@ -36,4 +36,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return sum_xor32(v);
 }
 
+// Per-jet maxima for the scales of the fp16 matrix kernels (kan_f16.hip): this lane's maxima of |value| per jet
+// slot -> maximum over the wave -> one integer atomic max per slot into out[0..3].  Non-negative floats order like
+// their bit patterns, and a maximum does not depend on the order of the atomics: results stay reproducible.
+__device__ __forceinline__ void publish_jet_absmax(float m0, float m1, float m2, float m3, unsigned* out) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m0 = fmaxf(m0, __shfl_xor(m0, d));
+    m1 = fmaxf(m1, __shfl_xor(m1, d));
+    m2 = fmaxf(m2, __shfl_xor(m2, d));
+    m3 = fmaxf(m3, __shfl_xor(m3, d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    // Thousands of waves combine into the same four words, and atomics on one address are served one after the
+    // other: look first (an L2 read; a stale, smaller value only costs an atomic that changes nothing) and add to
+    // the queue only when this wave would raise the maximum.  After the first few waves almost none does.
+    const float m[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned mine = __float_as_uint(m[j]);
+      if (mine > __hip_atomic_load(out + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + j, mine);
+    }
+  }
+}
+
 }  // namespace pdekan

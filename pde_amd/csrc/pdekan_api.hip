@@ -121,8 +121,10 @@ struct F16Io {
   unsigned* cot_out = nullptr;
 };
 
+// act_out (with a layer the sparse kernel takes): where that kernel leaves the per-jet maxima of y for an fp16
+// matrix layer above
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
-                float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr) {
+                float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr, unsigned* act_out = nullptr) {
   if (h && h->wpl && win) {
     // both on the same grid: the fp16 matrix kernel runs when every knot row is (nearly) equally spaced, else the
     // sparse kernel does (decided on the device)
@@ -131,7 +133,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
     pdekan::launch_fwd_sparse(L, a, win, y, n, st, true);
   } else if (win && pdekan::sparse_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.sparse", li);
-    pdekan::launch_fwd_sparse(L, a, win, y, n, st);
+    pdekan::launch_fwd_sparse(L, a, win, y, n, st, false, act_out);
   } else if (pdekan::mfma_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.mfma", li);
     pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
@@ -378,8 +380,11 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
     io.wpl = W.wpl[l]; io.act_in = S.act(l); io.wmax = S.w(l);
     io.act_out = (l + 1 < nl && W.wpl[l + 1]) ? S.act(l + 1) : nullptr;
   }
-  *act_ready = f16 && io.act_out != nullptr;
-  return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr);
+  // a layer the sparse kernel takes can leave the maxima of its outputs for an fp16 matrix layer above as well
+  unsigned* sparse_out = nullptr;
+  if (!f16 && l + 1 < nl && W.wpl[l + 1] && W.win[l] && pdekan::sparse_eligible(P.D, P.D2, P.L[l])) sparse_out = S.act(l + 1);
+  *act_ready = (f16 && io.act_out != nullptr) || sparse_out != nullptr;
+  return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out);
 }
 
 int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
@@ -592,13 +597,17 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     const int acc_flag = (accumulate || !first) ? 1 : 0;
     int top = nl - 1;            // first layer the generic backward loop still has to do
     int cur = 0;
+    bool head_left_cot = false;
     if (fused_head) {
       const int nblocks = pdekan::head_blocks(m, H);
+      // the head's input cotangents feed layer nl-2: leave their per-jet maxima if that layer runs on the fp16 kernels
+      unsigned* head_cot = (grads && nl > 1 && P.D == 2 && W.wpl[nl - 2]) ? S.cot(nl - 1) : nullptr;
+      head_left_cot = head_cot != nullptr;
       {
         ProfScope ps(st, "L%d.head_fused", nl - 1);
         pdekan::launch_head_bs(P.D, H, W.act[nl - 1], xs, stride_n, stride_d, tgt, W.wp[nl - 1], sigma, rate, inv_n,
                                res, (grads && nl > 1) ? W.g[0] : nullptr, grads ? W.part : nullptr, W.loss_part,
-                               nblocks, m, st);
+                               nblocks, m, st, head_cot);
         if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
       }
       if (grads) {
@@ -620,7 +629,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
     }
     if (grads) {
-      bool cot_ready = false;
+      bool cot_ready = head_left_cot;
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
         if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
