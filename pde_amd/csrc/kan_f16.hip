@@ -577,15 +577,39 @@ struct BwiF16 {
   static constexpr int kStageVecs = 2 * NB * 2 * 64;       // u32x4 per stage of W planes (input-gradient layout)
 };
 
-// basis with the third derivative for the chain rule: the interval is settled by comparisons against the knots
+// basis with the third derivative for the chain rule: the interval is settled by comparisons against the knots,
+// with one round of knot reads
 template <int ACT, bool GEN>
 __device__ __forceinline__ void eval_pair_d3(const float* knots, int nk, const FeatGrid& fg, float x, Basis& bs, Act& av) {
   if constexpr (GEN) eval_basis_near_uniform<true>(knots, nk, fg.g0, fg.glast, fg.inv_h, x, bs);
-  else eval_basis_uniform_straight<true>(knots, nk, fg.inv_h, x, bs);
+  else eval_basis_uniform_oneshot<true>(knots, nk, fg.g0, fg.glast, fg.inv_h, x, bs);
   av = eval_act(ACT, x);
 }
 
-template <int C1, int ACT, bool GEN>
+// what the chain rule of one (point, feature) pair needs once its gE columns are there
+struct PairBack { Basis bs; Act av; f32x4 x; };
+
+// gradient with respect to the input jet of one pair from the gE jets of its 4 + 1 live columns
+__device__ __forceinline__ f32x4 chain_rule(const PairBack& pb, const f32x4 (&dcol)[5], const f32x4& inv) {
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  const float s2 = pb.x[1] * pb.x[1];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const float e1 = m < 4 ? pb.bs.d1[m & 3] : pb.av.f1;
+    const float e2 = m < 4 ? pb.bs.d2[m & 3] : pb.av.f2;
+    const float e3 = m < 4 ? pb.bs.d3[m & 3] : pb.av.f3;
+    const f32x4 q = dcol[m] * inv;
+    out[0] += q[0] * e1 + (q[1] * pb.x[1] + q[2] * pb.x[2]) * e2 + q[3] * (s2 * e3 + pb.x[3] * e2);
+    out[1] += q[1] * e1 + 2.0f * pb.x[1] * q[3] * e2;
+    out[2] += q[2] * e1;
+    out[3] += q[3] * e1;
+  }
+  return out;
+}
+
+// N must be a multiple of 16 (whole waves; the caller gives the last N % 16 points to the sparse kernel).
+// MULTI: more than 64 outputs (several passes, read-modify-write of ga).
+template <int C1, int ACT, bool GEN, bool MULTI>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
                      const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
@@ -632,27 +656,23 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
   const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
   if (P0 >= N) return;                        // wave-uniform; no barrier below
   const int nst = I / 4;
-  int64_t prow = P0 + p_local;
-  const bool live_pt = prow < N;
-  if (!live_pt) prow = N - 1;
+  const int64_t prow = P0 + p_local;
   const char* xrow = reinterpret_cast<const char*>(a + prow * I + f_local);
   f32x4* orow = ga + prow * I + f_local;
   const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
   const float my_t = tj[r & 3];               // this lane's A-operand row is jet r & 3 of point r >> 2 of the m-tile
   f32x4 vmax = {0.f, 0.f, 0.f, 0.f};
-  const int npass = O / 64;
+  const int npass = MULTI ? O / 64 : 1;
 
   for (int ob = 0; ob < npass; ++ob) {
     // ---- the wave's gY rows of this output block -> A operands in registers ----
     u32x4 GAh[4][2], GAl[4][2];
     {
+      f32x4 graw[16];                         // 16 points x 64 outputs x 16 bytes, 1 KiB per instruction, all in flight
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {          // 16 points x 64 outputs x 16 bytes, 1 KiB per instruction
-        const int idx = lane + 64 * v, p = idx >> 6, o = idx & 63;
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (P0 + p < N) g = gy[(P0 + p) * O + ob * 64 + o];
-        *reinterpret_cast<f32x4*>(sD + p * GROW + o * 4) = g;
-      }
+      for (int v = 0; v < 16; ++v) graw[v] = gy[(P0 + v) * O + ob * 64 + lane];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) *reinterpret_cast<f32x4*>(sD + v * GROW + lane * 4) = graw[v];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -676,117 +696,92 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
     fetch_w(Wt[1], wbase + 128);
 
     f32x4 acc[4][NB];
-
-    // pipeline registers: the pair of the stage being multiplied (jet, basis) and of the stage before (gE columns)
-    f32x4 xcur = *reinterpret_cast<const f32x4*>(xrow), xnext = xcur;
-    if (nst > 1) xnext = *reinterpret_cast<const f32x4*>(xrow + 64);
-    f32x4 xprev = xcur, old = {0.f, 0.f, 0.f, 0.f};
-    Basis bprev;
-    Act aprev;
+    // pipeline registers: `cur` = the pair of the stage being multiplied, `prev` = the pair of the stage before with
+    // its gE columns.  Before the first stage `prev` is all zeros: its chain rule then rewrites what is already there.
+    PairBack prev, cur;
     f32x4 dcol[5];
-    bool have_prev = false;
+    f32x4 old = {0.f, 0.f, 0.f, 0.f};
+    if (MULTI && ob > 0) old = orow[0];
+    prev.x = (f32x4){0.f, 0.f, 0.f, 0.f};
+    prev.av = Act{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) prev.bs.d1[m] = prev.bs.d2[m] = prev.bs.d3[m] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) dcol[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    cur.x = *reinterpret_cast<const f32x4*>(xrow);
+    f32x4 xnext = (nst > 1) ? *reinterpret_cast<const f32x4*>(xrow + 64) : cur.x;
 
-    for (int s = 0; s <= nst; ++s) {           // one extra trip applies the chain rule of the last stage
-      const bool mul = s < nst;
-      const u32x4* wsrc = wbase + (size_t)(mul ? s : 0) * F::kStageVecs;
+    for (int s = 0; s < nst; ++s) {
+      const u32x4* wsrc = wbase + (size_t)s * F::kStageVecs;
       const u32x4* wnxt = wbase + (size_t)((s + 1 < nst) ? s + 1 : 0) * F::kStageVecs;
-      Basis bcur;
-      Act acur;
-      if (mul) {
+      f32x4* odst = orow + (s > 0 ? s - 1 : 0) * 4;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          const int ks = i / NB, n = i % NB;
-          {                                     // B operand of the region after the next
-            const int t = i + 2;
-            fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
-          }
-          if (i == 0 && have_prev) {            // chain rule of the stage before, on the columns read after its park
-            f32x4 out = {0.f, 0.f, 0.f, 0.f};
-            const float s2 = xprev[1] * xprev[1];
-#pragma unroll
-            for (int m = 0; m < 5; ++m) {
-              const float e1 = m < 4 ? bprev.d1[m & 3] : aprev.f1;
-              const float e2 = m < 4 ? bprev.d2[m & 3] : aprev.f2;
-              const float e3 = m < 4 ? bprev.d3[m & 3] : aprev.f3;
-              const f32x4 q = dcol[m] * inv;
-              out[0] += q[0] * e1 + (q[1] * xprev[1] + q[2] * xprev[2]) * e2 + q[3] * (s2 * e3 + xprev[3] * e2);
-              out[1] += q[1] * e1 + 2.0f * xprev[1] * q[3] * e2;
-              out[2] += q[2] * e1;
-              out[3] += q[3] * e1;
-            }
-            if (ob > 0) out += old;
-            if (live_pt) {
-              orow[(s - 1) * 4] = out;
-              if (ob == npass - 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(out[j]));
-              }
-            }
-          }
-          if (i == 1) {                         // this stage's pair: basis, activation (kept for the next stage)
-            const FeatGrid fg = {kbase[4 * s * KP], kbase[4 * s * KP + nk - 1], fabsf(kbase[4 * s * KP + (GEN ? nk + 4 : nk)])};
-            eval_pair_d3<ACT, GEN>(kbase + 4 * s * KP, nk, fg, xcur[0], bcur, acur);
-            if (ob > 0) old = orow[s * 4];
-          }
-          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};   // the first k-step starts the sums (no separate clearing pass)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
-                                                               __builtin_bit_cast(f16x8, Wt[i & 3].h),
-                                                               ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                               __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                               __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
-          if (i == 0) interleave<12, 8>(); else interleave<12, 4>();
-          __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < NR; ++i) {
+        const int ks = i / NB, n = i % NB;
+        {                                     // B operand of the region after the next
+          const int t = i + 2;
+          fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
         }
-        // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < NB; ++n) {
-            *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * n + r) * 4) = acc[m][n];
-          }
-        // the 4 + 1 live columns of this lane's pair (a column outside [0, C) reads the pad column: zero weight
-        // planes, so zero)
-        const float* drow = sD + p_local * ROW + (f_local * CP) * 4;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int c = bcur.c0 + m;
-          dcol[m] = (c >= 0 && c < C) ? *reinterpret_cast<const f32x4*>(drow + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        dcol[4] = *reinterpret_cast<const f32x4*>(drow + C * 4);
-        bprev = bcur; aprev = acur; xprev = xcur; have_prev = true;
-        xcur = xnext;
-        if (s + 2 < nst) xnext = *reinterpret_cast<const f32x4*>(xrow + (size_t)(s + 2) * 64);
-      } else {
-        // last trip: only the chain rule of the last stage
-        f32x4 out = {0.f, 0.f, 0.f, 0.f};
-        const float s2 = xprev[1] * xprev[1];
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-          const float e1 = m < 4 ? bprev.d1[m & 3] : aprev.f1;
-          const float e2 = m < 4 ? bprev.d2[m & 3] : aprev.f2;
-          const float e3 = m < 4 ? bprev.d3[m & 3] : aprev.f3;
-          const f32x4 q = dcol[m] * inv;
-          out[0] += q[0] * e1 + (q[1] * xprev[1] + q[2] * xprev[2]) * e2 + q[3] * (s2 * e3 + xprev[3] * e2);
-          out[1] += q[1] * e1 + 2.0f * xprev[1] * q[3] * e2;
-          out[2] += q[2] * e1;
-          out[3] += q[3] * e1;
-        }
-        if (ob > 0) out += old;
-        if (live_pt) {
-          orow[(s - 1) * 4] = out;
-          if (ob == npass - 1) {
+        if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
+          f32x4 out = chain_rule(prev, dcol, inv);
+          if (MULTI) out += old;
+          *odst = out;
+          if (!MULTI || ob == npass - 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(out[j]));
           }
         }
+        if (i == 1) {                         // this stage's pair: basis, activation (kept for the next stage)
+          const float* kn = kbase + 4 * s * KP;
+          const FeatGrid fg = {kn[0], kn[nk - 1], fabsf(kn[GEN ? nk + 4 : nk])};
+          eval_pair_d3<ACT, GEN>(kn, nk, fg, cur.x[0], cur.bs, cur.av);
+          if (MULTI) old = (ob > 0) ? orow[s * 4] : old;
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};   // the first k-step starts the sums (no separate clearing pass)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h),
+                                                             ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
+        if (i == 0) interleave<12, 10>(); else if (i == 1) interleave<12, 8>(); else interleave<12, 2>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * n + r) * 4) = acc[m][n];
+      // the 4 + 1 live columns of this lane's pair; a column outside [0, C) reads the base column's slot and is
+      // zeroed by a select (no branch)
+      const float* drow = sD + p_local * ROW + (f_local * CP) * 4;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = cur.bs.c0 + m;
+        const bool ok = (c >= 0) & (c < C);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(drow + (ok ? c : C) * 4);
+        dcol[m] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      dcol[4] = *reinterpret_cast<const f32x4*>(drow + C * 4);
+      prev = cur;
+      cur.x = xnext;
+      xnext = *reinterpret_cast<const f32x4*>(xrow + (size_t)((s + 2 < nst) ? s + 2 : 0) * 64);
+    }
+    {                                           // chain rule of the last stage
+      f32x4 out = chain_rule(prev, dcol, inv);
+      if (MULTI) out += old;
+      orow[(nst - 1) * 4] = out;
+      if (!MULTI || ob == npass - 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(out[j]));
       }
     }
   }
@@ -1150,7 +1145,7 @@ template <int C1, int ACT, bool GEN>
 static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                            const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
   using F = BwiF16<C1, ACT, GEN>;
-  auto k = bwd_input_f16_kernel<C1, ACT, GEN>;
+  auto k = (L.O > 64) ? bwd_input_f16_kernel<C1, ACT, GEN, true> : bwd_input_f16_kernel<C1, ACT, GEN, false>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * F::TILE) * 4;
   allow_lds(k, lds);
   k<<<(unsigned)((N + 63) / 64), 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(gy),
@@ -1170,7 +1165,8 @@ static void bwi_f16_variants(const LayerView& L, const float* a, const float* gy
   }
 }
 
-// cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr
+// cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr.
+// N must be a multiple of 16.
 void launch_bwd_input_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
                           const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
   const float* wplb = wpl + f16_wplane_floats(L) / 2;

@@ -64,8 +64,9 @@ void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStre
 // amax_out: where the per-jet maxima of y are combined into (4 words, see kan_f16.hip), or nullptr
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
                        bool skip_near_uniform = false, unsigned* amax_out = nullptr);
+// cot_out: where the per-jet maxima of ga are combined into (4 words), or nullptr
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                             int64_t N, hipStream_t st, bool skip_near_uniform = false);
+                             int64_t N, hipStream_t st, bool skip_near_uniform = false, unsigned* cot_out = nullptr);
 
 // kan_f16.hip: hidden layers on the fp16 matrix cores with fp32 accuracy (two fp16 pieces per operand, three
 // products), J = 4 jets; for layers whose knot rows are all (nearly) equally spaced - decided on the device

@@ -188,6 +188,24 @@ KAN_HD void eval_basis_uniform_straight(const KnotPtr g, int nk, float inv_h, fl
   uniform_cubic_pieces<kNeedD3>(t, out.inside, inv_h, out);
 }
 
+// The same again with ONE round of knot reads: the three knots the two corrections can ask for are read at once
+// (g[s-1], g[s], g[s+1] around the quotient guess s, indices clamped), then everything is selects in registers.
+// Same interval and same outputs as eval_basis_uniform_straight.
+template <bool kNeedD3, typename KnotPtr>
+KAN_HD void eval_basis_uniform_oneshot(const KnotPtr g, int nk, float g0, float glast, float inv_h, float x, Basis& out) {
+  const float u = (x - g0) * inv_h;
+  int s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
+  const float ga = g[s > 0 ? s - 1 : 0], gb = g[s], gc = g[s + 1];
+  const int down = (int)(s > 0) & (int)(x < gb);
+  const int up = (int)(s < nk - 2) & (int)(x >= gc) & (down ^ 1);
+  const float gs = down ? ga : (up ? gc : gb);
+  s += up - down;
+  out.c0 = s - kOrder;
+  out.inside = (int)(x >= g0) & (int)(x < glast);
+  const float t = out.inside ? (x - gs) * inv_h : 0.0f;
+  uniform_cubic_pieces<kNeedD3>(t, out.inside, inv_h, out);
+}
+
 // For kernels that need B, B' and B'' only (weight gradients): the interval comes from the quotient alone,
 // with g[0], g[nk-1] and 1/h passed in (registers), so the only knot read is g[s] and nothing depends on a
 // comparison against a neighbouring knot.  When rounding puts x a hair outside [g_s, g_{s+1}) the piece of the

@@ -367,7 +367,7 @@ template <int O, int RS = 64, bool MG = (RS != 64)>
 __global__ void __launch_bounds__(256, 2)
 bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
                         const float* __restrict__ ginfo, const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ ga,
-                        int64_t N, int I, int G, int act, int OTr, int skip_near_uniform) {
+                        int64_t N, int I, int G, int act, int OTr, int skip_near_uniform, unsigned* __restrict__ cot_out) {
   if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
   constexpr int OG = O / 32;
   constexpr int PW = 64 / OG;
@@ -393,7 +393,8 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
   float* sOw = sO + wave * PW * kFS * 4;
   // write the kFS gradients parked for features i0..i0+3: 4 lanes store the 64 contiguous bytes of a point
   const WaveRows<PW> wr = wave_rows<PW>(P0, N, I, lane);
-  auto flush_out = [&](int i0, bool add) {
+  f32x4 gmax = {0.f, 0.f, 0.f, 0.f};       // per-jet maxima of what the last pass stores (for cot_out)
+  auto flush_out = [&](int i0, bool add, bool last_pass) {
     float* dst = ga + (wr.base * I + i0) * 4;
 #pragma unroll
     for (int k = 0; k < WaveRows<PW>::NV; ++k) {
@@ -402,6 +403,10 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
         // a later pass adds to what this same lane stored at this address in the pass before
         if (MG && add) v += *reinterpret_cast<const f32x4*>(dst + wr.off[k]);
         *reinterpret_cast<f32x4*>(dst + wr.off[k]) = v;
+        if (last_pass) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gmax[j] = fmaxf(gmax[j], fabsf(v[j]));
+        }
       }
     }
   };
@@ -454,7 +459,7 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       if (i + 1 < I)
         table_stage<O, RS>(sT + (buf ^ 1) * O * RS, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane, OT, o0);
       if ((i % kFS) == 0) {
-        if (i > 0) flush_out(i - kFS, pass > 0);   // gradients of the previous 4 features, parked before the barrier
+        if (i > 0) flush_out(i - kFS, pass > 0, cot_out && pass == npass - 1);   // gradients of the previous 4 features, parked before the barrier
         if (i + kFS < I) jets_stage<PW>(sJw + (((i / kFS) + 1) & 1) * PW * kFS * 4, a, wr, I, i + kFS);
       }
       const float* tb = sT + buf * O * RS + (g * 32) * RS + L.slot * (RS == 64 ? 4 : 1);
@@ -518,8 +523,9 @@ bwd_input_sparse_kernel(const float* __restrict__ a, const float* __restrict__ g
       }
     }
     __syncthreads();
-    flush_out(I - kFS, pass > 0);
+    flush_out(I - kFS, pass > 0, cot_out && pass == npass - 1);
   }
+  if (cot_out) publish_jet_absmax(gmax[0], gmax[1], gmax[2], gmax[3], cot_out);
 }
 
 // ==========================================================================
@@ -610,21 +616,21 @@ void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, flo
 
 template <int O, int RS = 64, bool MG = (RS != 64)>
 static void bwd_input_sparse_launch(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                                    int64_t N, hipStream_t st, int skip) {
+                                    int64_t N, hipStream_t st, int skip, unsigned* cot_out) {
   const float* wbt = win + (size_t)L.I * L.O * RS;
   constexpr int pts = 4 * (64 / (O / 32));
   auto k = bwd_input_sparse_kernel<O, RS, MG>;
   const size_t lds = sparse_lds<O, RS>(L, true);
   big_lds(k, lds);
-  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O, skip);
+  k<<<(unsigned)((N + pts - 1) / pts), 256, lds, st>>>(a, gy, L.grid, L.ginfo, win, wbt, ga, N, L.I, L.G, L.act, L.O, skip, cot_out);
 }
 
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
-                             int64_t N, hipStream_t st, bool skip_near_uniform) {
+                             int64_t N, hipStream_t st, bool skip_near_uniform, unsigned* cot_out) {
   const int skip = skip_near_uniform ? 1 : 0;
-  if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st, skip);
-  else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st, skip);
-  else bwd_input_sparse_launch<64, 64, true>(L, a, gy, win, ga, N, st, skip);
+  if (!window_layout(L)) bwd_input_sparse_launch<64, kRawRow>(L, a, gy, win, ga, N, st, skip, cot_out);
+  else if (L.O == 64) bwd_input_sparse_launch<64>(L, a, gy, win, ga, N, st, skip, cot_out);
+  else bwd_input_sparse_launch<64, 64, true>(L, a, gy, win, ga, N, st, skip, cot_out);
 }
 
 }  // namespace pdekan

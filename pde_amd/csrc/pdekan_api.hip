@@ -130,7 +130,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
     // sparse kernel does (decided on the device)
     ProfScope ps(st, "L%d.fwd.mfma_f16x2", li);
     pdekan::launch_fwd_f16(L, a, h->wpl, y, n, h->act_in, h->wmax, h->act_out, st);
-    pdekan::launch_fwd_sparse(L, a, win, y, n, st, true);
+    pdekan::launch_fwd_sparse(L, a, win, y, n, st, true, h->act_out);
   } else if (win && pdekan::sparse_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.sparse", li);
     pdekan::launch_fwd_sparse(L, a, win, y, n, st, false, act_out);
@@ -179,8 +179,17 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
       // both on the same grid: the fp16 matrix kernel runs when every knot row is (nearly) equally spaced, else the
       // sparse kernel does (decided on the device)
       ProfScope ps(st, "L%d.bwd_input.mfma_f16x2", li);
-      pdekan::launch_bwd_input_f16(L, a, gy, h->wpl, ga, n, h->cot_in, h->wmax, h->cot_out, st);
-      pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st, true);
+      // (the matrix kernel walks whole groups of 16 points; the last n % 16 points always go to the sparse kernel)
+      const int64_t n16 = n / 16 * 16;
+      if (n16) {
+        pdekan::launch_bwd_input_f16(L, a, gy, h->wpl, ga, n16, h->cot_in, h->wmax, h->cot_out, st);
+        pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n16, st, true, h->cot_out);
+      }
+      if (n > n16) {
+        const size_t J = 4;
+        pdekan::launch_bwd_input_sparse(L, a + (size_t)n16 * L.I * J, gy + (size_t)n16 * L.O * J, win,
+                                        ga + (size_t)n16 * L.I * J, n - n16, st, false, h->cot_out);
+      }
     } else if (win && pdekan::sparse_input_grad_eligible(D, D2, L)) {
       ProfScope ps(st, "L%d.bwd_input.sparse", li);
       pdekan::launch_bwd_input_sparse(L, a, gy, win, ga, n, st);

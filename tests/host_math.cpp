@@ -113,6 +113,15 @@ void hm_eval_basis_uniform_straight(const float* knots, int nk, float x, float* 
   *c0 = bs.c0; *inside = bs.inside;
 }
 
+// the same with one round of knot reads (fp16 matrix input-gradient kernel)
+void hm_eval_basis_uniform_oneshot(const float* knots, int nk, float x, float* out16, int* c0, int* inside) {
+  const float h = (knots[nk - 1] - knots[0]) / (float)(nk - 1);
+  Basis bs;
+  eval_basis_uniform_oneshot<true>(knots, nk, knots[0], knots[nk - 1], 1.0f / h, x, bs);
+  for (int m = 0; m < 4; ++m) { out16[m] = bs.b[m]; out16[4 + m] = bs.d1[m]; out16[8 + m] = bs.d2[m]; out16[12 + m] = bs.d3[m]; }
+  *c0 = bs.c0; *inside = bs.inside;
+}
+
 // interval from the quotient alone (weight-gradient kernels: B, B', B'' only)
 void hm_eval_basis_uniform_by_quotient(const float* knots, int nk, float x, float* out16, int* c0, int* inside) {
   const float h = (knots[nk - 1] - knots[0]) / (float)(nk - 1);

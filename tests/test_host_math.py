@@ -132,6 +132,13 @@ def test_loop_free_equal_spacing_path_is_the_same_function(hm, G):
         if ia.value:
             assert ca.value == cb.value, x
         assert np.array_equal(a, b), x
+        # and the variant that reads the three candidate knots in one round (fp16 matrix input-gradient kernel)
+        hm.hm_eval_basis_uniform_oneshot(fptr(knots), len(knots), ctypes.c_float(x), fptr(b), ctypes.byref(cb),
+                                         ctypes.byref(ib))
+        assert ia.value == ib.value
+        if ia.value:
+            assert ca.value == cb.value, x
+        assert np.array_equal(a, b), x
 
 
 @pytest.mark.parametrize("G", [5, 10])
