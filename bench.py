@@ -80,6 +80,8 @@ def kernel_cost(name, widths, grid, n_pts, J):
         dense = 3.0 * dense
         byts = 4.0 * (J * 2 * I + widths[0]) * n_pts
         impl = "stream"
+    elif kind == "jet_absmax":              # per-jet maxima of a layer's input jets or output cotangents: one read
+        return 0.0, 0.0, PEAK_FP32_TFLOPS, 4.0 * J * max(I, O) * n_pts
     elif kind in ("gather_views", "scatter_views"):   # 12-jet tensor <-> 4-jet view of the widest side
         return 0.0, 0.0, PEAK_FP32_TFLOPS, 4.0 * (12 + 4) * max(I, O) * n_pts
     else:                                   # reduce_unpack: O(parameters)
@@ -99,9 +101,9 @@ def roofline_seconds(cost):
 
 
 HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<",
-                 "bwd_weight.mfma_f16x2": "bwd_weight_f16x2_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
-                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": "fwd_f16x2_kernel<",
-                 "bwd_input.mfma_f16x2": "bwd_input_f16x2_kernel<", "head_fused": "head_bs_kernel<"}
+                 "bwd_weight.mfma_f16x2": "bwd_weight_f16_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
+                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": "fwd_f16_kernel<",
+                 "bwd_input.mfma_f16x2": "bwd_input_f16_kernel<", "head_fused": "head_bs_kernel<"}
 
 
 def sources_digest():

@@ -1058,9 +1058,9 @@ bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy,
 // ==========================================================================================================
 // host side
 // ==========================================================================================================
-static bool f16_disabled() {
-  static const bool off = [] { const char* v = getenv("PDEKAN_DISABLE_F16"); return v && v[0] == '1'; }();
-  return off;
+static bool f16_disabled() {                 // A/B switch for tests and profiling
+  const char* v = getenv("PDEKAN_DISABLE_F16");
+  return v && v[0] == '1';
 }
 
 // layers the fp16 matrix kernels take (whether they run is settled on the device from the knot rows)

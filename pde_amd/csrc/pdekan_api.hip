@@ -103,10 +103,22 @@ size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
   return pdekan::sparse_eligible(D, D2, L) ? pdekan::sparse_table_floats(L) : 0;
 }
 
-size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+// layers of a layer-level call that the fp16 matrix kernels take (they need the sparse tables as their fallback)
+bool layer_f16(int D, int D2, const pdekan::LayerView& L) {
+  return pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0;
+}
+constexpr size_t kLayerStatWords = 64;   // act / cot / w maxima of a layer-level call, 4 words each (256 bytes)
+
+// tables of a layer forward: packed weights (two orders), sparse tables, knot-row classes, fp16 planes and maxima
+size_t layer_fwd_floats(int D, int D2, const pdekan::LayerView& L) {
   const size_t packed = align_up(L.packed_floats() * 4) / 4;
-  return 2 * packed + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4 +
-         align_up(win_floats(D, D2, L) * 4) / 4 + align_up((size_t)L.I * 4) / 4;
+  size_t f = 2 * packed + align_up(win_floats(D, D2, L) * 4) / 4 + align_up((size_t)L.I * 4) / 4;
+  if (layer_f16(D, D2, L)) f += align_up(pdekan::f16_wplane_floats(L) * 4) / 4 + kLayerStatWords;
+  return f;
+}
+
+size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  return layer_fwd_floats(D, D2, L) + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4;
 }
 
 // What the fp16 matrix kernels of a layer need beside the layer itself: its W planes, the per-jet maxima of its
@@ -396,6 +408,35 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
   return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out);
 }
 
+// Tables of one layer-level call, carved from the caller's workspace in this order.
+struct LayerTables { float *wp, *wt, *win, *ginfo, *wpl; unsigned* stats; };   // stats: act [0..3], cot [4..7], w [8]
+
+bool carve_layer(Carver& c, int D, int D2, const pdekan::LayerView& L, bool with_win, LayerTables& T) {
+  T.wp = c.take(L.packed_floats());
+  T.wt = c.take(L.packed_floats());
+  const bool f16 = layer_f16(D, D2, L);
+  const size_t wf = (with_win || f16) ? win_floats(D, D2, L) : 0;
+  T.win = wf ? c.take(wf) : nullptr;
+  T.ginfo = c.take(L.I);
+  T.wpl = f16 ? c.take(pdekan::f16_wplane_floats(L)) : nullptr;
+  T.stats = f16 ? reinterpret_cast<unsigned*>(c.take(kLayerStatWords)) : nullptr;
+  return c.ok;
+}
+
+int pack_layer(pdekan::LayerView& L, const LayerTables& T, hipStream_t st) {
+  pdekan::launch_grid_info(L, T.ginfo, st);
+  L.ginfo = T.ginfo;
+  pdekan::launch_pack_weights(L, T.wp, T.wt, st);
+  if (T.win) pdekan::launch_pack_window(L, T.wp, T.win, st);
+  if (T.wpl) {
+    if (hipMemsetAsync(T.stats, 0, kLayerStatWords * 4, st) != hipSuccess)
+      return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
+    pdekan::launch_absmax(T.wp, (int64_t)L.packed_floats(), T.stats + 8, st);
+    pdekan::launch_pack_wplanes16(L, T.wp, T.stats + 8, T.wpl, st);
+  }
+  return PDEKAN_OK;
+}
+
 int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n, int32_t n_dir,
                        int32_t n_second, void* ws, size_t ws_bytes, void* stream) {
   pdekan::LayerView L;
@@ -405,18 +446,18 @@ int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_je
   if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
   if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
   Carver c(ws, ws_bytes);
-  float* wp = c.take(L.packed_floats());
-  float* wt = c.take(L.packed_floats());
-  const size_t wf = win_floats(n_dir, n_second, L);
-  float* win = wf ? c.take(wf) : nullptr;
-  float* ginfo = c.take(L.I);
-  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  LayerTables T;
+  if (!carve_layer(c, n_dir, n_second, L, true, T))
+    return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  pdekan::launch_grid_info(L, ginfo, st);
-  L.ginfo = ginfo;
-  pdekan::launch_pack_weights(L, wp, wt, st);
-  if (win) pdekan::launch_pack_window(L, wp, win, st);
-  return run_forward(n_dir, n_second, L, x_jet, wt, win, y_jet, n, st);
+  rc = pack_layer(L, T, st);
+  if (rc) return rc;
+  F16Io io;
+  if (T.wpl) {
+    pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats, st);
+    io.wpl = T.wpl; io.act_in = T.stats; io.wmax = T.stats + 8;
+  }
+  return run_forward(n_dir, n_second, L, x_jet, T.wt, T.win, y_jet, n, st, 0, T.wpl ? &io : nullptr);
 }
 
 // ---- built-in scratch of pdekan_layer_forward_noalloc ------------------------------------------------------
@@ -480,7 +521,7 @@ int pdekan_layer_forward_noalloc(const PdekanLayer* layer, const float* x_jet, f
   if (rc) return rc;
   if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
   // the packed tables do not depend on n: size them for one point
-  const size_t need = layer_ws_floats(n_dir, n_second, L, 1) * sizeof(float);
+  const size_t need = layer_fwd_floats(n_dir, n_second, L) * sizeof(float);
   if (need > kScratchBytes)
     return fail(PDEKAN_ERR_WORKSPACE,
                 "layer_forward_noalloc: a %d -> %d layer at grid %d needs %zu bytes of packed tables, the built-in "
@@ -502,19 +543,21 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   if (!jet_supported(n_dir, n_second)) return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", n_dir, n_second);
   if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
   Carver c(ws, ws_bytes);
-  float* wp = c.take(L.packed_floats());
-  float* wt = c.take(L.packed_floats());
+  LayerTables T;
+  const bool tables_ok = carve_layer(c, n_dir, n_second, L, gx_jet != nullptr, T);
   float* part = c.take((size_t)(weight_chunks(n_dir, n_second, L, n) + 1) * L.packed_floats());
-  const size_t wf = (gx_jet != nullptr) ? win_floats(n_dir, n_second, L) : 0;
-  float* win = wf ? c.take(wf) : nullptr;
-  float* ginfo = c.take(L.I);
-  if (!c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  if (!tables_ok || !c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  pdekan::launch_grid_info(L, ginfo, st);
-  L.ginfo = ginfo;
-  pdekan::launch_pack_weights(L, wp, wt, st);
-  if (win) pdekan::launch_pack_window(L, wp, win, st);
-  return run_backward(n_dir, n_second, L, x_jet, gy_jet, wp, win, gx_jet, part, grads, accumulate, n, st);
+  rc = pack_layer(L, T, st);
+  if (rc) return rc;
+  F16Io io;
+  if (T.wpl) {
+    pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats, st);
+    pdekan::launch_jet_absmax(gy_jet, n * L.O, T.stats + 4, st);
+    io.wpl = T.wpl; io.act_in = T.stats; io.cot_in = T.stats + 4; io.wmax = T.stats + 8;
+  }
+  return run_backward(n_dir, n_second, L, x_jet, gy_jet, T.wp, T.win, gx_jet, part, grads, accumulate, n, st, 0,
+                      T.wpl ? &io : nullptr);
 }
 
 size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers, int64_t n, int32_t n_dir,

@@ -1,0 +1,127 @@
+"""The fp16 two-piece matrix-core kernels (forward, input gradients, weight gradients of hidden layers with
+(nearly) equally spaced knots) against the fp32 kernels on the same inputs and against fp64 tensor math, one layer
+at a time through the layer-level entry points of the C ABI."""
+import pytest
+import torch
+
+from conftest import max_rel
+from oracle import kan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(I, O_, G, knots, seed):
+    from pde_amd.kan import KANLinear
+    torch.manual_seed(seed)
+    lay = KANLinear(I, O_, grid_size=G, grid_range=[-1.25, 1.25] if knots == "exact" else [-1, 1]).cuda()
+    with torch.no_grad():
+        for p in lay.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+        if knots == "jittered":                       # still within h/4 of equal spacing: the nearly-equal variant
+            lay.grid[:, 5] += 0.01
+            lay.grid[::3, 9] -= 0.004
+        if knots == "moved":                          # far from equal spacing: the kernels must step aside
+            lay.grid[:, 6] += 0.09
+    return lay
+
+
+def _run(lay, xj, gy):
+    for p in lay.parameters():
+        p.grad = None
+    x = xj.clone().requires_grad_(True)
+    y = lay.forward_jet(x, 2, 1)
+    y.backward(gy)
+    return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in lay.parameters()]
+
+
+def _jets(N, I, O_, seed, jet_scale=(1.0, 1.0, 1.0, 1.0), cot_scale=(1.0, 1.0, 1.0, 1.0)):
+    g = torch.Generator().manual_seed(seed)
+    xj = torch.randn(N, I, 4, generator=g) * torch.tensor(jet_scale)
+    xj[:, :, 0] = torch.rand(N, I, generator=g) * 3.6 - 1.8          # also outside the extended grid
+    gy = torch.randn(N, O_, 4, generator=g) * torch.tensor(cot_scale)
+    return xj.cuda(), gy.cuda()
+
+
+NAMES = ["y", "gx", "base_weight", "spline_weight", "spline_scaler"]
+
+
+@pytest.mark.parametrize("I,O_,N,G,knots", [
+    (64, 64, 4099, 10, "default"), (8, 64, 48, 10, "default"), (16, 128, 1000, 10, "default"),
+    (128, 128, 2064, 10, "default"), (256, 256, 1024, 10, "default"), (64, 256, 333, 10, "default"),
+    (32, 64, 17, 10, "default"), (64, 64, 15, 10, "default"), (64, 64, 1000, 10, "jittered"),
+    (64, 64, 2000, 20, "default"), (32, 64, 48, 20, "exact"), (256, 256, 1040, 20, "default"),
+    (64, 128, 4099, 20, "default"), (48, 192, 500, 20, "exact")])
+def test_fp16_kernels_agree_with_the_fp32_kernels(I, O_, N, G, knots, monkeypatch):
+    """Every block / pass decode of the three kernels (1 to 4 output blocks, 2 to 64 stages, ragged N with the
+    sparse-kernel tail, the accumulator flush of wide layers) against the fp32 vector / matrix kernels.  Knot rows:
+    default grid 10 = equally spaced; default grid 20 and "jittered" = nearly (general triangle); "exact" = grid 20
+    on [-1.25, 1.25], equally spaced."""
+    lay = _layer(I, O_, G, knots, I + O_)
+    xj, gy = _jets(N, I, O_, N)
+    a = _run(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16", "1")
+    b = _run(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16")
+    for name, u, v in zip(NAMES, a, b):
+        # heavy-tailed random jets: each kernel's fp32 accumulation alone sits 1e-6 to 3e-6 from an fp64 sum here
+        assert max_rel(u.cpu(), v.cpu()) <= 5e-6, (name, max_rel(u.cpu(), v.cpu()))
+    assert not torch.equal(a[0], b[0])                                      # the switch selected something
+    if N >= 16:                                                             # (fewer points: all of them are the sparse-kernel tail)
+        assert not torch.equal(a[1], b[1])
+    if I >= 32 and N >= 1000:                                            # (smaller N: one chunk, fp32 matrix kernel either way)
+        assert not torch.equal(a[3], b[3])
+
+
+def test_knot_rows_far_from_equal_spacing_fall_back_bit_for_bit(monkeypatch):
+    lay = _layer(64, 64, 10, "moved", 3)
+    xj, gy = _jets(1000, 64, 64, 4)
+    a = _run(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16", "1")
+    b = _run(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16")
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("jet_scale,cot_scale", [
+    ((1.0, 1e3, 1e-3, 1e6), (1e-9, 1e-6, 1e-12, 1e-9)),       # second derivatives 10^6 above values, tiny cotangents
+    ((1.0, 1e-4, 1e4, 1e-8), (1e5, 1e-3, 1e2, 1e6)),
+    ((1.0, 1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0)),              # whole jet slots of the cotangent zero
+])
+def test_per_jet_scales_cover_wide_dynamic_ranges(jet_scale, cot_scale):
+    """The operands are scaled per jet slot into fp16's range before they are cut in two; jets that differ by many
+    orders of magnitude (and slots that are zero throughout) must neither overflow nor lose their small slots.
+    Against fp64 tensor math on the same layer, slot by slot."""
+    I, O_, N, G = 64, 64, 1024, 10
+    lay = _layer(I, O_, G, "default", 9)
+    xj, gy = _jets(N, I, O_, 10, jet_scale, cot_scale)
+    y, gx, gb, gs, gc = _run(lay, xj, gy)
+    assert all(torch.isfinite(t).all() for t in (y, gx, gb, gs, gc))
+    # fp64 reference of the jet forward by autograd on the oracle's dense layer
+    p64 = {"grid": lay.grid.double().cpu(), "base_weight": lay.base_weight.detach().double().cpu(),
+           "spline_weight": lay.spline_weight.detach().double().cpu(),
+           "spline_scaler": lay.spline_scaler.detach().double().cpu()}
+    leaves = {k: p64[k].clone().requires_grad_(True) for k in ("base_weight", "spline_weight", "spline_scaler")}
+    q = dict(p64, **leaves)
+    x64 = xj.double().cpu()
+    a0 = x64[:, :, 0].clone().requires_grad_(True)
+    a1, a2, a3 = (x64[:, :, j].clone().requires_grad_(True) for j in (1, 2, 3))
+    # y0 = f(a0); y1 = J a1; y2 = J a2; y3 = a1^T H a1 (diagonal: per-feature second derivative) + J a3, with f separable
+    f = O.layer_forward(a0, q, "silu")                                   # [N, O]
+    yref = torch.zeros(N, O_, 4, dtype=torch.float64)
+    cols = []
+    for o in range(O_):
+        (g1,) = torch.autograd.grad(f[:, o].sum(), a0, create_graph=True)           # d f_o / d a0_i  [N, I]
+        (g2,) = torch.autograd.grad((g1 * a1).sum(), a0, create_graph=True)      # f''_oi a1_i per feature (f is separable)
+        cols.append(torch.stack([f[:, o], (g1 * a1).sum(1), (g1 * a2).sum(1), (g2 * a1).sum(1) + (g1 * a3).sum(1)], -1))
+    yfull = torch.stack(cols, 1)                                          # [N, O, 4], differentiable
+    for j in range(4):
+        assert max_rel(y[:, :, j].cpu(), yfull[:, :, j].detach()) <= 1e-5, ("y", j)
+    loss = (yfull * gy.double().cpu()).sum()
+    grads = torch.autograd.grad(loss, [a0, a1, a2, a3] + [leaves[k] for k in ("base_weight", "spline_weight", "spline_scaler")])
+    gxref = torch.stack(grads[:4], -1)
+    for j in range(4):
+        if gxref[:, :, j].abs().max() > 0:
+            assert max_rel(gx[:, :, j].cpu(), gxref[:, :, j]) <= 1e-5, ("gx", j)
+    for name, got, ref in zip(NAMES[2:], (gb, gs, gc), grads[4:]):
+        assert max_rel(got.cpu(), ref) <= 1e-5, name
