@@ -77,6 +77,15 @@ const char* pdekan_last_error(void);
 int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t n, int32_t d,
                      int32_t n_dir, int32_t n_second, float* jet, void* stream);
 
+/* KANLinear.b_splines (kan.py:78-111), dense, and its derivatives with respect to x as autograd would form them:
+ * out[N][in][grid_size + spline_order] = d^order B_c(x[n][i]) / dx^order for x[N][in] (contiguous), order 0..3
+ * (half-open knot intervals, zero outside the extended grid; the fourth derivative of a cubic is zero).  This is
+ * the one piece of KANLinear.forward that torch.func transforms (jacrev / hessian, run1.py:122-124) cannot trace
+ * through a library call: with it as an elementwise op that knows its own derivative, forward under those
+ * transforms is two GEMMs around this kernel. */
+int pdekan_basis_dense(const float* grid, const float* x, int64_t n, int32_t in_features, int32_t grid_size,
+                       int32_t spline_order, int32_t order, float* out, void* stream);
+
 /* KANLinear.forward (kan.py:153-166) on jets: y_jet[N][out][J] from
  * x_jet[N][in][J].  With (n_dir, n_second) = (0,0) this is exactly the
  * reference forward; otherwise the derivative slots carry what autograd /

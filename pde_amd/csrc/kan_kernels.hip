@@ -517,6 +517,32 @@ void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, b
   gather_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(in12, reinterpret_cast<float4*>(out4), elems, k, keep_value ? 1 : 0);
 }
 
+// Dense bases of every feature, or their derivative of the given order with respect to x:
+// out[N][I][C] = d^order B_c(x[n][i]) / dx^order (b_splines, efficient_kan/kan.py:78-111, and what autograd makes
+// of it).  One thread per (point, feature): local evaluation of the 4 live bases (general knots, half-open
+// intervals), written out with the zeros around them.
+__global__ void basis_dense_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
+                                   int64_t total, int I, int nk, int C, int order) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t % I);
+    Basis bs;
+    eval_basis<true>(grid + (size_t)i * nk, nk, x[t], bs);
+    const float* v = order == 0 ? bs.b : (order == 1 ? bs.d1 : (order == 2 ? bs.d2 : bs.d3));
+    float* dst = out + t * C;
+    for (int c = 0; c < C; ++c) {
+      const int m = c - bs.c0;
+      dst[c] = (m >= 0 && m < 4) ? v[m] : 0.0f;
+    }
+  }
+}
+
+void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st) {
+  const int64_t total = N * I;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  basis_dense_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, grid, out, total, I, G + 2 * kOrder + 1, G + kOrder, order);
+}
+
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st) {
   grid_info_kernel<<<(L.I + 63) / 64, 64, 0, st>>>(L.grid, ginfo, L.I, L.nk());
 }

@@ -130,3 +130,69 @@ def kan_layer(x, grid, base_weight, spline_weight, spline_scaler, act_kind, grid
     y = _KanLayerJet.apply(x.contiguous().unsqueeze(-1), grid, base_weight, spline_weight, spline_scaler,
                            act_kind, grid_size, spline_order, 0, 0)
     return y.squeeze(-1)
+
+
+class _BasisDense(torch.autograd.Function):
+    """Dense B-spline bases ``[N, in, coeff]`` of ``x [N, in]`` or their ``order``-th derivative with respect to
+    ``x``, as ONE elementwise kernel that knows its own derivative: the backward (and the forward-mode rule) of
+    order k is order k+1 times the incoming tangent / cotangent, order 4 of a cubic is zero, and a batched call
+    folds the batch into the rows.  That closes the op under ``torch.func`` transforms of any depth (``jacrev``,
+    ``hessian``, ``vmap``, ``grad``), which is what lets ``KANLinear.forward`` stay on the GPU kernels under them."""
+
+    generate_vmap_rule = False
+
+    @staticmethod
+    def forward(x, grid, order, grid_size, spline_order):
+        _require_gpu(x, "x")
+        lib = _lib.load()
+        xd = x.detach().contiguous()
+        gd = grid.detach().contiguous()
+        n, in_f = xd.shape
+        out = torch.empty(n, in_f, grid_size + spline_order, dtype=torch.float32, device=x.device)
+        if n > 0:
+            with torch.cuda.device(x.device):
+                _lib.check(lib.pdekan_basis_dense(_ptr(gd), _ptr(xd), n, in_f, grid_size, spline_order, order,
+                                                  _ptr(out), _stream(x.device)))
+        return out
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, grid, order, grid_size, spline_order = inputs
+        ctx.save_for_backward(x, grid)
+        ctx.save_for_forward(x, grid)
+        ctx.meta = (order, grid_size, spline_order)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, grid = ctx.saved_tensors
+        order, grid_size, spline_order = ctx.meta
+        if order >= spline_order:                      # derivative of a piecewise constant
+            return torch.zeros_like(x), None, None, None, None
+        nxt = _BasisDense.apply(x, grid, order + 1, grid_size, spline_order)
+        return (gout * nxt).sum(-1), None, None, None, None
+
+    @staticmethod
+    def jvp(ctx, x_t, grid_t, *_):
+        x, grid = ctx.saved_tensors
+        order, grid_size, spline_order = ctx.meta
+        if x_t is None or order >= spline_order:
+            return torch.zeros(x.shape + (grid_size + spline_order,), dtype=x.dtype, device=x.device)
+        return _BasisDense.apply(x, grid, order + 1, grid_size, spline_order) * x_t.unsqueeze(-1)
+
+    @staticmethod
+    def vmap(info, in_dims, x, grid, order, grid_size, spline_order):
+        x_bdim, grid_bdim = in_dims[0], in_dims[1]
+        if grid_bdim is not None:
+            raise NotImplementedError("pde_amd: a batched knot grid under vmap is not supported")
+        if x_bdim is None:
+            return _BasisDense.apply(x, grid, order, grid_size, spline_order), None
+        xb = x.movedim(x_bdim, 0)                      # [B, N, in]: the op is row-wise, so the batch folds into N
+        b, n, in_f = xb.shape
+        out = _BasisDense.apply(xb.reshape(b * n, in_f), grid, order, grid_size, spline_order)
+        return out.view(b, n, in_f, -1), 0
+
+
+def basis_dense(x: torch.Tensor, grid: torch.Tensor, grid_size: int, spline_order: int, order: int = 0) -> torch.Tensor:
+    """``b_splines`` (kan.py:78-111) of ``x [N, in]`` on the GPU kernel, ``[N, in, grid_size + spline_order]``;
+    differentiable in ``x`` to any order and usable under ``torch.func`` transforms."""
+    return _BasisDense.apply(x, grid, order, grid_size, spline_order)

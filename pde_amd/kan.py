@@ -86,6 +86,8 @@ class KANLinear(torch.nn.Module):
     def b_splines(self, x: torch.Tensor):
         """Dense bases ``(batch, in_features, grid_size + spline_order)`` (kan.py:78-111)."""
         assert x.dim() == 2 and x.size(1) == self.in_features
+        if x.is_cuda and self.spline_order == 3 and x.dtype == torch.float32:
+            return K.basis_dense(x, self.grid, self.grid_size, self.spline_order)     # the library's basis kernel
         return dense_bsplines(x, self.grid, self.spline_order)
 
     def curve2coeff(self, x: torch.Tensor, y: torch.Tensor):
@@ -117,12 +119,18 @@ class KANLinear(torch.nn.Module):
         grid, bw, sw, sc = self._kernel_params()
         if _under_func_transform(flat):
             # torch.func transforms (the scripts' jacrev / hessian, run1.py:122-124) trace through tensor ops and
-            # cannot see inside a library call: under them the layer is its defining expression (kan.py:153-166)
-            # in differentiable tensor ops on whatever device the input lives on.  O(n^2)/O(n^3) like the scripts;
-            # forward_jet gives the same derivatives in O(n).
+            # cannot see inside a whole-layer library call.  Under them the layer is its defining expression
+            # (kan.py:153-166): two GEMMs around the dense bases.  On a GPU the bases come from the library's
+            # basis kernel, an elementwise op that carries its own derivative, vmap and forward-mode rules
+            # (functional.basis_dense), so jacrev / hessian of any depth stay on it; on a CPU tensor (no kernels
+            # there) they are plain tensor code.  O(n^2)/O(n^3) like the scripts either way; forward_jet gives the
+            # same derivatives in O(n).
+            if grid.is_cuda and self.spline_order == 3:
+                bases = K.basis_dense(flat, grid, self.grid_size, self.spline_order)
+            else:
+                bases = dense_bsplines(flat, grid, self.spline_order)
             base = F.linear(self.base_activation(flat), bw)
-            spline = F.linear(dense_bsplines(flat, grid, self.spline_order).view(flat.size(0), -1),
-                              self.scaled_spline_weight.view(self.out_features, -1))
+            spline = F.linear(bases.reshape(flat.size(0), -1), self.scaled_spline_weight.view(self.out_features, -1))
             return (base + spline).view(*lead, self.out_features)
         if kind is not None:
             out = K.kan_layer(flat, grid, bw, sw, sc, kind, self.grid_size, self.spline_order)

@@ -179,3 +179,49 @@ def test_data_parallel_wrapper_on_a_one_rank_rccl_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_jacrev_hessian_callers_stay_on_the_kernels_and_train(golden, monkeypatch):
+    """run1.py:120-129 and :145-149 as written - jacrev / hessian through `forward`, residual, loss.backward() -
+    on a GPU model with the tensor-code bases switched off: the dense-basis kernel (an elementwise op that carries
+    its own derivative, vmap and forward-mode rules) must serve every transform level, and the parameter gradients
+    that come back through those transforms must be the fused step's."""
+    import pde_amd.kan as kan_mod
+    from torch.func import hessian, jacrev
+    from pde_amd.pinn import BS_RATE, BS_SIGMA, BlackScholesStep
+    from test_gpu_parity import build_model
+
+    def refuse(*a, **k):
+        raise AssertionError("tensor-code b_splines used on a GPU tensor")
+
+    monkeypatch.setattr(kan_mod, "dense_bsplines", refuse)
+    rec = golden("jacrev_hessian")
+    m = build_model(rec)
+    x = torch.from_numpy(rec["x"][:, 0].copy()).cuda()
+    t = torch.from_numpy(rec["x"][:, 1].copy()).cuda()
+
+    def net(xx, tt):
+        return m(torch.stack([xx.reshape(-1), tt.reshape(-1)]).permute(1, 0))[:, 0]
+
+    s = net(x, t)
+    s_x = jacrev(net, argnums=0)(x, t).sum(dim=0)
+    s_xx = hessian(net, argnums=0)(x, t).sum(dim=0).sum(dim=0)
+    s_t = jacrev(net, argnums=1)(x, t).sum(dim=0)
+    for val, key in ((s, "s"), (s_x, "s_x"), (s_xx, "s_xx"), (s_t, "s_t")):
+        assert max_rel(val.detach().cpu(), rec[key]) <= TOL, key
+    res = s_t - 0.5 * BS_SIGMA ** 2 * x ** 2 * s_xx - BS_RATE * x * s_x + BS_RATE * s          # run1.py:128
+    loss = torch.mean(res ** 2)                                                                 # run1.py:148
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()                                                                             # run1.py:225
+    got = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    step = BlackScholesStep(m)
+    loss_fused = step(torch.stack([x, t], 1))
+    assert abs(loss.item() - loss_fused.item()) <= TOL * abs(loss_fused.item())
+    assert max_rel(got.cpu(), step.flat_grad.cpu()) <= TOL
+    # the module's b_splines method on a GPU tensor is the same kernel; against the tensor code on the CPU
+    monkeypatch.undo()
+    lay = m.layers[0]
+    xs = torch.rand(300, lay.in_features, generator=torch.Generator().manual_seed(1)) * 3.4 - 1.7
+    from pde_amd.spline_host import dense_bsplines
+    assert max_rel(lay.b_splines(xs.cuda()).cpu(), dense_bsplines(xs, lay.grid.cpu(), 3)) <= 2e-6
