@@ -122,6 +122,41 @@ class BlackScholesStep:
         return self.loss
 
 
+class GraphedStep:
+    """The fused step on ONE fixed batch, captured in a HIP graph and replayed per call.
+
+    For optimisers that evaluate the same batch many times per update - the LBFGS scripts call their closure up to
+    25 times per step (run2.py:174-199, kan/LBFGS.py:228-229) - a replay costs one graph launch instead of a
+    dozen kernel launches plus the host code around them.  Parameters are read from their own storage at replay,
+    so in-place updates (what torch.optim does) are seen; the batch is the captured copy ``x`` (``copy_`` into it to
+    change points without re-capturing).  Use as an LBFGS closure::
+
+        g = GraphedStep(BlackScholesStep(model), x)
+        def closure():
+            opt.zero_grad()
+            return g()
+    """
+
+    def __init__(self, step: BlackScholesStep, x: torch.Tensor, target: Optional[torch.Tensor] = None,
+                 n_global: Optional[int] = None):
+        self.step = step
+        self.x = x.detach().clone()
+        self.target = None if target is None else target.detach().clone()
+        self.n_global = n_global
+        step(self.x, target=self.target, n_global=n_global)        # allocates the workspace outside the capture
+        torch.cuda.synchronize(step.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            step(self.x, target=self.target, n_global=n_global)
+
+    def __call__(self) -> torch.Tensor:
+        for p, v in zip(self.step.model.parameters(), self.step._views):
+            if p.grad is not v:            # e.g. after optimizer.zero_grad(set_to_none=True)
+                p.grad = v
+        self.graph.replay()
+        return self.step.loss
+
+
 def bs_residual_from_jet(x: torch.Tensor, jet: torch.Tensor, sigma: float = BS_SIGMA, rate: float = BS_RATE):
     """Residual of run1.py:128 from ``KAN.forward_jet`` output ``[N, 1, J]``
     in ordinary tensor ops (a handful of [N]-sized ops; differentiable)."""

@@ -231,7 +231,63 @@ def make_deeponet(name, sensors, w12, w4, w5, seed, n, bc_weight, steps=3):
     print(f"{name}: loss={float(rec['loss']):.6e} adamw={rec['adamw_losses']} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_lbfgs_trace(name="lbfgs_trace", outer_steps=3, max_iter=6):
+    """The LBFGS training variant (run2.py:174-199, 测试.py:124): the reference KAN driven by the reference's own
+    vendored optimiser (kan/LBFGS.py:185-483, loaded from its file: the `kan` package around it needs libraries
+    this container lacks) with the Black-Scholes residual loss as the closure, a few outer steps on one fixed batch.
+    Stored: the initial state, the batch, the loss of EVERY closure evaluation in order, and the parameters after
+    each outer step."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_vendored_lbfgs", os.path.join(REF, "kan", "LBFGS.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(21)
+    widths, grid_size = [2, 8, 1], 5
+    model = KAN(widths, grid_size=grid_size)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.rand(512, 2, generator=gen)
+    rec = {"widths": np.array(widths), "grid_size": np.array(grid_size), "act": np.array("silu"), "x": x.numpy(),
+           "outer_steps": np.array(outer_steps), "max_iter": np.array(max_iter)}
+    for k, v in model.state_dict().items():
+        rec[f"sd.{k}"] = v.detach().clone().numpy()
+    opt = mod.LBFGS(model.parameters(), lr=1.0, max_iter=max_iter, history_size=10, line_search_fn="strong_wolfe",
+                    tolerance_grad=1e-32, tolerance_change=1e-32, tolerance_ys=1e-32)
+    evals = []
+
+    def closure():
+        opt.zero_grad()
+        xr, v, g1, sec = jets_autograd(model, x, 1)
+        loss = (residual(xr, v, g1, sec) ** 2).mean()
+        loss.backward()
+        evals.append(float(loss))
+        return loss
+
+    counts = []
+    for k in range(outer_steps):
+        opt.step(closure)
+        counts.append(len(evals))
+        for name_, v in model.state_dict().items():
+            rec[f"after{k}.{name_}"] = v.detach().clone().numpy()
+    rec["closure_losses"] = np.array(evals, np.float64)
+    rec["evals_after_step"] = np.array(counts)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {len(evals)} closure evaluations, loss {evals[0]:.4e} -> {evals[-1]:.4e}")
+
+
+def make_data_quotes(name="data_quotes"):
+    """The 72 market quotes the scripts score against (data.csv: K, X, T, V; run1.py:492-507) as arrays."""
+    rows = np.loadtxt(os.path.join(REF, "data.csv"), delimiter=",", skiprows=1)
+    assert rows.shape == (72, 4)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), K=rows[:, 0], X=rows[:, 1], T=rows[:, 2], V=rows[:, 3])
+    print(f"{name}: {rows.shape[0]} quotes")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--extras":      # only the fixtures added later
+        make_lbfgs_trace()
+        make_data_quotes()
+        sys.exit(0)
     make("cfg1_silu", [2, 5, 1], 5, "silu", 0, 200)
     make("cfg1_identity", [2, 5, 1], 5, "identity", 1, 200)
     make("cfg1_init", [2, 5, 1], 5, "silu", 0, 64, perturb=False)
@@ -244,3 +300,5 @@ if __name__ == "__main__":
     make_jacrev_case()
     make_deeponet("deeponet_run1", 12, [3, 2, 1], [12, 2, 1], [2, 6, 1], 11, 16, 8.0)      # shapes of run1.py:478-482
     make_deeponet("deeponet_wide", 10, [3, 2, 1], [10, 2, 2], [2, 5, 2], 12, 20, 200.0)    # latent width 2 (the 3-branch script's model4)
+    make_lbfgs_trace()
+    make_data_quotes()
