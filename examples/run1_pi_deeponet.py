@@ -7,9 +7,9 @@ What differs from the script, on purpose:
     this image does not have); the distributions and shapes are the script's,
     except that the time column of the second sensor network is a regular grid
     where the script interpolates a Gaussian-process draw (run1.py:283-297);
-  * the market file data.csv is not shipped; the trained network is scored
-    against the closed-form European call (the formula of B-S.py:5-17) on a grid
-    of (S, t) instead, with the script's error measures (run1.py:511-523);
+  * besides the script's evaluation on the 72 market quotes of data.csv (run1.py:492-523; the quotes are kept
+    as arrays in tests/golden/data_quotes.npz) the trained network is also scored against the closed-form
+    European call (the formula of B-S.py:5-17) on a grid of (S, t), with the script's error measures;
   * the network classes are pde_amd's (HIP kernels), not efficient_kan's.
 
     python examples/run1_pi_deeponet.py --epochs 50
@@ -164,7 +164,37 @@ def main(argv=None):
     mape = (torch.mean(torch.abs((s_true[mask] - s_pred[mask]) / s_true[mask])) * 100).item()
     print(f"MSE: {mse:.6e}\nRMSE: {math.sqrt(mse):.6e}\nMAPE (in-the-money points): {mape:.3f}%")
     print(f"run-time: {train_s:.2f} s for {args.epochs} epochs x {min(len(dl1), len(dl2))} steps")
-    return {"history": history, "mse": mse, "mape": mape, "train_s": train_s}
+    out = {"history": history, "mse": mse, "mape": mape, "train_s": train_s}
+    quotes = market_quotes()
+    if quotes is not None:
+        out["market"] = score_on_quotes(lambda x, t: net.operator_net(data["u_1"], data["u_2"], u_s1, u_s2, x, t),
+                                        quotes, norm, dev)
+        print("market quotes (data.csv): MSE: {mse:.6e}  RMSE: {rmse:.6e}  MAPE: {mape:.3f}%".format(**out["market"]))
+    return out
+
+
+QUOTES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data_quotes.npz")
+
+
+def market_quotes(path: str = QUOTES):
+    """The reference's data.csv (columns K, X, T, V: strike, spot, days to expiry, quoted price) as arrays."""
+    if not os.path.exists(path):
+        return None
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in ("K", "X", "T", "V")}
+
+
+def score_on_quotes(operator, quotes, norm, dev):
+    """run1.py:492-523: spot and T/365 normalised with the training ranges, prediction scaled back by the largest
+    training price, MSE / RMSE / MAPE against the quoted prices."""
+    x = torch.tensor(min_max_normalize(quotes["X"], *norm["x"]), dtype=torch.float32, device=dev)
+    t = torch.tensor(min_max_normalize(quotes["T"] / 365.0, *norm["t"]), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        s_pred = operator(x, t) * float(norm["s"][1])
+    s_true = torch.tensor(quotes["V"], dtype=torch.float32, device=dev)
+    mse = torch.mean((s_pred - s_true) ** 2).item()
+    mape = (torch.mean(torch.abs((s_true - s_pred) / s_true)) * 100).item()
+    return {"mse": mse, "rmse": math.sqrt(mse), "mape": mape, "n": int(s_true.numel())}
 
 
 if __name__ == "__main__":

@@ -30,3 +30,16 @@ def test_finite_differences_agree_with_the_closed_form():
     # the scheme as the reference writes it loses the far boundary: the last interior node collapses
     f = fdm_call_grid(T, r, v, M, K)
     assert f[0, M - 1] < 0.5 * (3 * K - K)
+
+
+def test_market_quotes_fixture_is_the_references_file():
+    """tests/golden/data_quotes.npz holds the 72 rows of the reference's data.csv (K, X, T, V): one strike, days to
+    expiry counting down, positive prices - and the closed form with the scripts' constants (run1.py:126-127,
+    429-434) prices them within the spread the scripts report against (tens of percent)."""
+    import numpy as np
+    from conftest import load_golden
+    q = load_golden("data_quotes")
+    assert all(q[k].shape == (72,) for k in ("K", "X", "T", "V"))
+    assert np.all(q["K"] == 2.411) and np.all(q["V"] > 0) and q["T"].max() == 121
+    model = closed_form_call(q["X"], 2.411, q["T"] / 365.0, 0.025610, 0.165856529)
+    assert np.median(np.abs(model - q["V"]) / q["V"]) < 0.5

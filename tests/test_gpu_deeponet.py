@@ -105,6 +105,8 @@ def test_example_training_run_learns(graph):
     assert torch.isfinite(hist).all()
     assert hist[-3:, 1].mean() < hist[:3, 1].mean()
     assert out["mse"] == out["mse"]
+    # the script's evaluation on its 72 market quotes (run1.py:492-523): scored, finite
+    assert out["market"]["n"] == 72 and out["market"]["mape"] == out["market"]["mape"]
 
 
 def test_trained_pinn_prices_the_call():
