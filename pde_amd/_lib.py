@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdekan.so")
+# PDEKAN_LIB: another build of the same library (A/B timing of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("PDEKAN_LIB") or os.path.join(_HERE, "libpdekan.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 

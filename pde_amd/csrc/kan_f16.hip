@@ -256,15 +256,25 @@ __device__ __forceinline__ void mfma3x4(f32x4 (&acc)[4], u32x4 ah, u32x4 al, con
     acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, __builtin_bit_cast(f16x8, bh[n]), acc[n], 0, 0, 0);
 }
 
+#ifndef PDEKAN_SCHED_VARIANT
+#define PDEKAN_SCHED_VARIANT 0
+#endif
 // scheduling hint for a fenced region: CNT matrix instructions, each followed by up to PER other instructions
 template <int CNT, int PER>
 __device__ __forceinline__ void interleave() {
+#if PDEKAN_SCHED_VARIANT == 0 || PDEKAN_SCHED_VARIANT == 3
 #pragma unroll
   for (int k = 0; k < CNT; ++k) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
-    __builtin_amdgcn_sched_group_barrier(0x3b2, PER, 0);         // VALU / VMEM / DS
+    __builtin_amdgcn_sched_group_barrier(0x3b2, PDEKAN_SCHED_VARIANT == 3 ? 2 : PER, 0);         // VALU / VMEM / DS
   }
+#endif
 }
+#if PDEKAN_SCHED_VARIANT == 2
+#define PDEKAN_REGION_FENCE()
+#else
+#define PDEKAN_REGION_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // ==========================================================================================================
 // W planes.  CP = columns per feature in the K index (C1 rounded up so that 4 features are whole k-steps of 32:
@@ -399,7 +409,7 @@ struct FwdF16 {
       cur = nxt;
       nxt = far;
       if (i == 0) interleave<12, 8>(); else interleave<12, 4>();
-      __builtin_amdgcn_sched_barrier(0);
+      PDEKAN_REGION_FENCE();
     }
   }
 };
@@ -752,7 +762,7 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
                                                              __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
         if (i == 0) interleave<12, 10>(); else if (i == 1) interleave<12, 8>(); else interleave<12, 2>();
-        __builtin_amdgcn_sched_barrier(0);
+        PDEKAN_REGION_FENCE();
       }
       // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c
 #pragma unroll
