@@ -1066,6 +1066,305 @@ bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy,
 }
 
 // ==========================================================================================================
+// 12 jets per scalar (5 assets + time: value, 6 first derivatives, 5 second derivatives; the basket model).
+// A scalar's jets are three groups of four slots, and every (point, group) is a "virtual point" with four rows:
+//   group 0: value, d/dx0, d/dx1, d/dx2      group 1: d/dx3, d/dx4, d/dx5, d2/dx0^2      group 2: d2/dx1^2 .. d2/dx4^2
+// Row r of a group is  al_r * B + be_r * B' + ga_r * B''  of the live bases (and of the activation), with
+//   value: (1, 0, 0)      d/dx_k: (0, a[1+k], 0)      d2/dx_k^2: (0, a[7+k], a[1+k]^2)
+// (kan_math.h, jet_accumulate), each multiplied by its slot's scale.  Forward and input gradients take 8 points x 3
+// groups = 6 row tiles per wave; the weight gradients walk the virtual points of their chunk 8 at a time.
+// ==========================================================================================================
+constexpr int kRowWords12 = 56;              // 8 points x 12 slots x fp16 = 192 bytes + 32 bytes of padding; 8 * 7: conflict-free as above
+
+struct SlotScales12 { float s[12]; };
+
+// Upper bounds of the expanded rows from the per-slot maxima of the input jets (12 words) -> one scale per slot
+__device__ __forceinline__ SlotScales12 expanded_slot_scales12(const unsigned* amax, float inv_h_max) {
+  float a[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) a[j] = __uint_as_float(amax[j]);
+  const float c1 = fmaxf(1.1f, 1.5f * inv_h_max), c2 = fmaxf(0.5f, 3.0f * inv_h_max * inv_h_max);
+  SlotScales12 r;
+  r.s[0] = pow2_scale(fmaxf(1.0f, a[0]));
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.s[1 + k] = pow2_scale(c1 * a[1 + k]);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) r.s[7 + k] = pow2_scale(c2 * a[1 + k] * a[1 + k] + c1 * a[7 + k]);
+  return r;
+}
+
+// out[j] = max(out[j], bits of max |t[e][j]|), j < 12, over e < n: per-slot maxima of a 12-jet tensor [...][12]
+__global__ void jet_absmax12_kernel(const f32x4* __restrict__ t, int64_t n, unsigned* __restrict__ out) {
+  f32x4 m[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const f32x4 v0 = t[3 * e], v1 = t[3 * e + 1], v2 = t[3 * e + 2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[0][j] = fmaxf(m[0][j], fabsf(v0[j])); m[1][j] = fmaxf(m[1][j], fabsf(v1[j])); m[2][j] = fmaxf(m[2][j], fabsf(v2[j]));
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) publish_jet_max(m[g], out + 4 * g, threadIdx.x & 63);
+}
+
+struct PairCols12 { f32x4 col[5][3]; int c0; };            // [4 live columns + base column][group] x 4 rows
+struct Planes12 { u32x2 h[3], l[3]; };                     // one column: 3 groups x 4 rows, two planes
+
+// row coefficients of the three groups of one input jet, scaled: be[g][r] multiplies B', ga[g][r] multiplies B''
+// (group 0 row 0 is the value row: s[0] * B)
+struct RowCoefs12 { f32x4 be[3]; f32x4 ga[3]; float s0; };
+
+__device__ __forceinline__ RowCoefs12 row_coefs12(const f32x4 (&x)[3], const SlotScales12& sc) {
+  RowCoefs12 rc;
+  const float a1 = x[0][1], a2 = x[0][2], a3 = x[0][3], a4 = x[1][0], a5 = x[1][1];
+  rc.s0 = sc.s[0];
+  rc.be[0] = (f32x4){0.f, a1 * sc.s[1], a2 * sc.s[2], a3 * sc.s[3]};
+  rc.be[1] = (f32x4){a4 * sc.s[4], a5 * sc.s[5], x[1][2] * sc.s[6], x[1][3] * sc.s[7]};
+  rc.be[2] = (f32x4){x[2][0] * sc.s[8], x[2][1] * sc.s[9], x[2][2] * sc.s[10], x[2][3] * sc.s[11]};
+  rc.ga[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  rc.ga[1] = (f32x4){0.f, 0.f, 0.f, a1 * a1 * sc.s[7]};
+  rc.ga[2] = (f32x4){a2 * a2 * sc.s[8], a3 * a3 * sc.s[9], a4 * a4 * sc.s[10], a5 * a5 * sc.s[11]};
+  return rc;
+}
+
+template <int ACT, bool GEN>
+__device__ __forceinline__ void expand12(const float* knots, int nk, const FeatGrid& fg, const f32x4 (&x)[3],
+                                         const SlotScales12& sc, PairCols12& out) {
+  Basis bs;
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
+  const Act av = eval_act(ACT, x[0][0]);
+  const RowCoefs12 rc = row_coefs12(x, sc);
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const float b0 = m < 4 ? bs.b[m & 3] : av.f0, b1 = m < 4 ? bs.d1[m & 3] : av.f1, b2 = m < 4 ? bs.d2[m & 3] : av.f2;
+    out.col[m][0] = rc.be[0] * b1;
+    out.col[m][0][0] = rc.s0 * b0;
+    out.col[m][1] = rc.be[1] * b1;
+    out.col[m][1][3] += rc.ga[1][3] * b2;
+    out.col[m][2] = rc.be[2] * b1 + rc.ga[2] * b2;
+  }
+  out.c0 = bs.c0;
+}
+
+__device__ __forceinline__ Planes12 split_col12(const f32x4 (&c)[3]) {
+  Planes12 p;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const Planes16 q = split_jet16(c[g]);
+    p.h[g] = q.h;
+    p.l[g] = q.l;
+  }
+  return p;
+}
+
+// E tile row (one expanded column): [group][8 points][4 rows] fp16 = 3 x 16 words (+ pad); row tile 2g + (p >> 2)
+// of the A operand is the 8 words at 16g + 8(p >> 2)
+template <int C1, int PLANE>
+__device__ __forceinline__ void park_pair12(unsigned* base, unsigned* dump, const Planes12 (&pp)[5], int c0, int& prev_c0) {
+  constexpr int C = C1 - 1;
+  const u32x2 zero = {0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = prev_c0 + m;
+    unsigned* dst = (c >= 0 && c < C) ? base + c * kRowWords12 : dump;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      *reinterpret_cast<u32x2*>(dst + 16 * g) = zero;
+      *reinterpret_cast<u32x2*>(dst + 16 * g + PLANE) = zero;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = (m < 4) ? c0 + m : C;
+    unsigned* dst = (m == 4 || (c >= 0 && c < C)) ? base + c * kRowWords12 : dump;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      *reinterpret_cast<u32x2*>(dst + 16 * g) = pp[m].h[g];
+      *reinterpret_cast<u32x2*>(dst + 16 * g + PLANE) = pp[m].l[g];
+    }
+  }
+  prev_c0 = c0;
+}
+
+// ---- forward, 12 jets: wave = 8 points x 3 groups = 6 row tiles x 64 outputs (24 accumulator tiles), one wave per
+// SIMD.  Stage = 4 features = KS k-steps x 6 row tiles = 6*KS regions of 12 matrix instructions.  Lanes 32..63
+// repeat the pairs of lanes 0..31 (same values to the same LDS words).  N must be a multiple of 8.
+template <int C1, int ACT, bool GEN>
+struct Fwd12 {
+  static constexpr int CP = (C1 + 7) / 8 * 8;
+  static constexpr int KS = CP / 8;
+  static constexpr int NR = 6 * KS;
+  static constexpr int ROWS = 4 * C1 + 2;          // + a row of zeros (padding columns) + a dump row (columns off the grid)
+  static constexpr int PLANE = ROWS * kRowWords12;
+  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int nk = C1 + 3;
+  static constexpr int kStepVecs = 4 * 2 * 64;
+  static constexpr int kStageVecs = KS * kStepVecs;
+
+  //   region 0            basis and rows of the next stage's pairs (scaled)
+  //   region 1            fetch the input jets of the stage after the next
+  //   regions 1 .. 5      cut one column each
+  //   region NR-2         park the next stage's planes
+  template <bool FLIP>
+  static __device__ __forceinline__ void stage(f32x4 (&acc)[6][4], WTiles16& Wa, WTiles16& Wb, ATile16& cur, ATile16& nxt,
+                                               f32x4 (&xraw)[3], unsigned* sE, const float* knots_next,
+                                               const SlotScales12& sc, int& prev_c0, const u32x4* __restrict__ wsrc,
+                                               const u32x4* __restrict__ wnext, const char* __restrict__ xnext2,
+                                               const int (&aoff)[KS][2], int lane) {
+    const int p_local = lane & 7, f_local = (lane >> 3) & 3;
+    PairCols12 pj;
+    Planes12 pp[5];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int ks = i / 6, m = i % 6;
+      const bool odd = ((ks & 1) != 0) != FLIP;
+      WTiles16& Wc = odd ? Wb : Wa;
+      WTiles16& Wn = odd ? Wa : Wb;
+      if (m < 4) load_w16(Wn, (ks + 1 < KS) ? wsrc + (ks + 1) * kStepVecs : wnext, lane, m);
+      if (i == 0) {
+        const FeatGrid fg = {knots_next[0], knots_next[nk - 1], fabsf(knots_next[GEN ? nk + 4 : nk])};
+        expand12<ACT, GEN>(knots_next, nk, fg, xraw, sc, pj);
+      }
+      if (i == 1) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xraw[g] = *reinterpret_cast<const f32x4*>(xnext2 + 16 * g);
+      }
+      if (i >= 1 && i <= 5) pp[i - 1] = split_col12(pj.col[i - 1]);
+      if (i == NR - 2) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): retire the reads in flight before the run of writes
+        unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
+        park_pair12<C1, PLANE>(base, sE + (ROWS - 1) * kRowWords12 + p_local * 2, pp, pj.c0, prev_c0);
+      }
+      const int t2 = (i + 2) % NR;
+      const ATile16 far = read_atile16<PLANE>(sE, aoff[t2 / 6][0], aoff[t2 / 6][1], t2 % 6);
+      mfma3x4(acc[m], cur.h, cur.l, Wc.h, Wc.l);
+      cur = nxt;
+      nxt = far;
+      if (i == 0) interleave<12, 12>(); else interleave<12, 4>();
+      PDEKAN_REGION_FENCE();
+    }
+  }
+};
+
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+fwd12_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                 const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
+                 const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
+  using F = Fwd12<C1, ACT, GEN>;
+  constexpr int KS = F::KS, KP = F::KP, nk = F::nk, CP = F::CP;
+  constexpr int kWaveWords = 2 * F::PLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  {
+    bool near = true, equal = true;
+    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+      const float gi = ginfo[i < I ? i : 0];
+      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+    }
+    if (!near || equal == GEN) return;
+  }
+  float* sK = reinterpret_cast<float*>(smem);
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + I * KP + wave * kWaveWords;
+  if constexpr (GEN) {
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  for (int idx = lane; idx < kWaveWords; idx += 64) sE[idx] = 0u;
+  const SlotScales12 sc = expanded_slot_scales12(amax_in, max_inv_h(ginfo, I, lane));
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  __syncthreads();
+
+  const int r = lane & 15, kb = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) & 3;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 8;
+  if (P0 >= N) return;
+  const int o0 = blockIdx.y * 64;
+  const int nst = I / 4;
+  int aoff[KS][2];
+  {
+    const int q_ = (lane & 15) >> 2, p_ = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int col = ks * 32 + kstep_col(kb, half * 4 + q_);
+        const int row = ((col % CP) < C1) ? (col / CP) * C1 + (col % CP) : F::ROWS - 2;
+        aoff[ks][half] = row * kRowWords12 + 2 * p_;
+      }
+  }
+  const char* xrow = reinterpret_cast<const char*>(a + ((P0 + p_local) * I + f_local) * 3);
+  constexpr size_t kStageBytes = 4 * 48;                                    // 4 features x 12 floats
+  const u32x4* wbase = wpl + (size_t)blockIdx.y * nst * F::kStageVecs;
+  const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
+
+  f32x4 acc[6][4], tot[6][4];
+#pragma unroll
+  for (int m = 0; m < 6; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  WTiles16 WA, WB;
+  int prev_c0 = -100;
+  f32x4 xraw[3];
+  {
+    f32x4 x0[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      x0[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+      xraw[g] = *reinterpret_cast<const f32x4*>(xrow + kStageBytes + 16 * g);
+    }
+    const FeatGrid fg = {kbase[0], kbase[nk - 1], fabsf(kbase[GEN ? nk + 4 : nk])};
+    PairCols12 pj;
+    Planes12 pp[5];
+    expand12<ACT, GEN>(kbase, nk, fg, x0, sc, pj);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) pp[m] = split_col12(pj.col[m]);
+    unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
+    park_pair12<C1, F::PLANE>(base, sE + (F::ROWS - 1) * kRowWords12 + p_local * 2, pp, pj.c0, prev_c0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) load_w16(WA, wbase, lane, n);
+  }
+  ATile16 cur = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 0);
+  ATile16 nxt = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 1);
+  for (int s = 0; s < nst; s += 2) {
+    const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : 0, s3 = (s + 3 < nst) ? s + 3 : 0;
+    F::template stage<false>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s1 * KP, sc, prev_c0,
+                             wbase + (size_t)s * F::kStageVecs, wbase + (size_t)s1 * F::kStageVecs,
+                             xrow + (size_t)s2 * kStageBytes, aoff, lane);
+    F::template stage<(KS & 1) != 0>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s2 * KP, sc, prev_c0,
+                                     wbase + (size_t)s1 * F::kStageVecs, wbase + (size_t)s2 * F::kStageVecs,
+                                     xrow + (size_t)s3 * kStageBytes, aoff, lane);
+    if (((s + 2) % kFwdFlushStages) == 0) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { tot[m][n] += acc[m][n]; acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+  // D[(p, slot)][output]: row tile m = 2g + pq; this lane holds slots 4g .. 4g+3 of point 4pq + kb for output 16n + r
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const int g = m >> 1, pq = m & 1;
+    f32x4 inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[4 * g + j] * sw);
+    const int64_t p = P0 + 4 * pq + kb;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) y[(p * O + o0 + 16 * n + r) * 3 + g] = (acc[m][n] + tot[m][n]) * inv;
+  }
+}
+
+// ==========================================================================================================
 // host side
 // ==========================================================================================================
 static bool f16_disabled() {                 // A/B switch for tests and profiling
@@ -1077,6 +1376,13 @@ static bool f16_disabled() {                 // A/B switch for tests and profili
 bool f16_eligible(int D, int D2, const LayerView& L) {
   if (D != 2 || D2 != 1 || f16_disabled()) return false;
   if (L.G != 10 && L.G != 20) return false;
+  return L.I >= 8 && L.I % 8 == 0 && L.I <= 256 && L.O % 64 == 0 && L.O <= 256;
+}
+
+// 12-jet layers (6 directions, 5 second derivatives) the fp16 matrix kernels take
+bool f16_jets12_eligible(int D, int D2, const LayerView& L) {
+  if (D != 6 || D2 != 5 || f16_disabled()) return false;
+  if (L.G != 10) return false;                       // one wave's E tile of a grid-20 layer does not fit beside three others
   return L.I >= 8 && L.I % 8 == 0 && L.I <= 256 && L.O % 64 == 0 && L.O <= 256;
 }
 
@@ -1100,6 +1406,13 @@ void launch_jet_absmax(const float* t, int64_t elems, unsigned* out4, hipStream_
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   jet_absmax_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const f32x4*>(t), elems, out4);
+}
+
+void launch_jet_absmax12(const float* t, int64_t elems, unsigned* out12, hipStream_t st) {
+  int64_t blocks = (elems + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  jet_absmax12_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const f32x4*>(t), elems, out12);
 }
 
 // wp[O][I][C1] -> the two W plane images; wmax: bits of max |wp| (launch_absmax)
@@ -1149,6 +1462,30 @@ void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float*
                     const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
   if (L.G == 10) fwd_f16_variants<14>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
   else fwd_f16_variants<24>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+}
+
+template <int ACT, bool GEN>
+static void fwd12_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
+                         const unsigned* amax_in, const unsigned* wmax, hipStream_t st) {
+  using F = Fwd12<14, ACT, GEN>;
+  auto k = fwd12_f16_kernel<14, ACT, GEN>;
+  const size_t lds = ((size_t)L.I * F::KP + 4 * 2 * F::PLANE) * 4;
+  allow_lds(k, lds);
+  dim3 g((unsigned)((N + 31) / 32), L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wpl),
+                         reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax);
+}
+
+// 12-jet forward (f16_jets12_eligible layers): amax_in = per-slot maxima of a (12 words).  N must be a multiple of 8.
+void launch_fwd12_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
+                      const unsigned* wmax, hipStream_t st) {
+  if (L.act == kActSiLU) {
+    fwd12_launch<kActSiLU, false>(L, a, wpl, y, N, amax_in, wmax, st);
+    fwd12_launch<kActSiLU, true>(L, a, wpl, y, N, amax_in, wmax, st);
+  } else {
+    fwd12_launch<kActIdentity, false>(L, a, wpl, y, N, amax_in, wmax, st);
+    fwd12_launch<kActIdentity, true>(L, a, wpl, y, N, amax_in, wmax, st);
+  }
 }
 
 template <int C1, int ACT, bool GEN>

@@ -101,8 +101,10 @@ template <int D, int D2>
 __global__ void __launch_bounds__(256)
 fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                    const float* __restrict__ wt, float* __restrict__ y,
-                   int64_t N, int I, int O, int G, int act, int PT, int NIC, int i0, int IB, int accumulate) {
+                   int64_t N, int I, int O, int G, int act, int PT, int NIC, int i0, int IB, int accumulate,
+                   int skip_near_uniform) {
   constexpr int J = 1 + D + D2;
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // a matrix kernel beside this one takes the layer
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
   const int IBe = (I - i0 < IB) ? (I - i0) : IB;          // features of this window
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -485,7 +487,8 @@ static inline int pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; retu
 // cotangent's value jet is taken in pass 0 only.  in[e][12] -> out[e][4].
 // --------------------------------------------------------------------------
 __global__ void gather_jets4_kernel(const float* __restrict__ in, float4* __restrict__ out, int64_t total, int k,
-                                    int keep_value) {
+                                    int keep_value, const float* __restrict__ skip_ginfo, int skip_I) {
+  if (skip_ginfo && all_rows_near_uniform(skip_ginfo, skip_I)) return;    // nobody reads the view: see JetSkip
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const float* src = in + e * 12;
     out[e] = make_float4(keep_value ? src[0] : 0.0f, src[1 + k], k == 0 ? src[6] : 0.0f, src[7 + k]);
@@ -494,7 +497,9 @@ __global__ void gather_jets4_kernel(const float* __restrict__ in, float4* __rest
 
 // the way back for input gradients: pass k of the 4-jet kernel gives (its share of d/d value, d/d first k,
 // d/d time in pass 0, d/d second k); the value shares add up over the passes.  in4[e] -> out12[e][12].
-__global__ void scatter_jets4_kernel(const float4* __restrict__ in, float* __restrict__ out, int64_t total, int k) {
+__global__ void scatter_jets4_kernel(const float4* __restrict__ in, float* __restrict__ out, int64_t total, int k,
+                                     const float* __restrict__ skip_ginfo, int skip_I) {
+  if (skip_ginfo && all_rows_near_uniform(skip_ginfo, skip_I)) return;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = in[e];
     float* dst = out + e * 12;
@@ -505,16 +510,19 @@ __global__ void scatter_jets4_kernel(const float4* __restrict__ in, float* __res
   }
 }
 
-void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st) {
+void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st, JetSkip skip) {
   int64_t blocks = (elems + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  scatter_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(in4), out12, elems, k);
+  scatter_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(in4), out12, elems, k,
+                                                         skip.ginfo, skip.I);
 }
 
-void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st) {
+void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st,
+                         JetSkip skip) {
   int64_t blocks = (elems + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  gather_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(in12, reinterpret_cast<float4*>(out4), elems, k, keep_value ? 1 : 0);
+  gather_jets4_kernel<<<(unsigned)blocks, 256, 0, st>>>(in12, reinterpret_cast<float4*>(out4), elems, k, keep_value ? 1 : 0,
+                                                        skip.ginfo, skip.I);
 }
 
 // Dense bases of every feature, or their derivative of the given order with respect to x:
@@ -568,7 +576,7 @@ static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, 
 constexpr int kGenericWindow = 256;
 
 template <int D, int D2>
-static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st) {
+static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st, bool skip) {
   constexpr int J = 1 + D + D2;
   int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
   const int per_feature = (int)sizeof(EdgeRec) + J * 4 + (L.nk() + 1) * 4;
@@ -585,7 +593,7 @@ static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y,
   const int64_t blocks = (N + PT - 1) / PT;
   for (int i0 = 0; i0 < L.I; i0 += IB)
     fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act,
-                                                                  PT, NIC, i0, IB, i0 > 0);
+                                                                  PT, NIC, i0, IB, i0 > 0, skip ? 1 : 0);
 }
 
 template <int D, int D2>
@@ -663,8 +671,8 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t sn, int64_t sd, flo
 }
 
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st) {
-#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st)
+                        hipStream_t st, bool skip_near_uniform) {
+#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
   return true;

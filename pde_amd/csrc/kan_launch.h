@@ -20,19 +20,24 @@ struct LayerView {
   size_t packed_floats() const { return (size_t)O * I * C1(); }
 };
 
+// A launch that the 12-jet matrix kernels of kan_f16.hip replace when every knot row of the layer is (nearly) equally
+// spaced (settled on the device from the layer's ginfo): with ginfo set, the kernel returns at once in that case.
+struct JetSkip { const float* ginfo = nullptr; int I = 0; };
+
 // kan_kernels.hip
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st);
 // out[N][I][G+3] = order-th derivative of every cubic basis at x[N][I]
 void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st);
 // out4[e] = (value or 0, first k, first 5 in pass 0 else 0, second k) of in12[e], e < elems, k = 0..4
-void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st);
+void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st,
+                         JetSkip skip = {});
 // out12[e] <- pass k's (value share, first k, time in pass 0, second k); the value shares are summed over k = 0..4
-void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st);
+void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st, JetSkip skip = {});
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st);
 bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
                       int I, hipStream_t st);
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st);
+                        hipStream_t st, bool skip_near_uniform = false);
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
                               const float* wp, float* ga, int64_t N, hipStream_t st);
 int generic_weight_chunks(int64_t N, int I, int O);
@@ -83,6 +88,12 @@ void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float*
 // cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr
 void launch_bwd_input_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
                           const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st);
+// 12-jet layers (6 directions, 5 second derivatives; grid 10): same planes, per-slot maxima are 12 words;
+// N must be a multiple of 8
+bool f16_jets12_eligible(int D, int D2, const LayerView& L);
+void launch_jet_absmax12(const float* t, int64_t elems, unsigned* out12, hipStream_t st);   // per-slot maxima of [elems][12]
+void launch_fwd12_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
+                      const unsigned* wmax, hipStream_t st);
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);

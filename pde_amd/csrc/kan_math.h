@@ -379,4 +379,17 @@ KAN_HD void jet_pullback_coeffs(const float* gy, const float* a, float& A0, floa
   A1 = s1; A2 = s2;
 }
 
+#ifdef __HIPCC__
+// Block-uniform: every feature's knot row is equally spaced or nearly so (ginfo != 0, see knot_spacing_info): the
+// condition under which the fp16 matrix kernels of kan_f16.hip run; kernels that work beside them then leave the layer to them.
+__device__ __forceinline__ bool all_rows_near_uniform(const float* ginfo, int I) {
+  if (!ginfo) return false;
+  const int lane = threadIdx.x & 63;
+  bool near = true;
+  for (int i = lane; i < ((I + 63) & ~63); i += 64)
+    near = near && (__builtin_amdgcn_ballot_w64(ginfo[i < I ? i : 0] != 0.0f) == ~0ull);
+  return near;
+}
+#endif
+
 }  // namespace pdekan

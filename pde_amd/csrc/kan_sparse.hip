@@ -105,17 +105,6 @@ __device__ __forceinline__ void barrier_after_dma() {
   __syncthreads();
 }
 
-// Block-uniform: every feature's knot row is equally spaced or nearly so (ginfo != 0, see knot_spacing_info): the
-// condition under which the fp16 matrix kernels of kan_f16.hip run; the kernels here then leave the layer to them.
-__device__ __forceinline__ bool all_rows_near_uniform(const float* ginfo, int I) {
-  if (!ginfo) return false;
-  const int lane = threadIdx.x & 63;
-  bool near = true;
-  for (int i = lane; i < ((I + 63) & ~63); i += 64)
-    near = near && (__builtin_amdgcn_ballot_w64(ginfo[i < I ? i : 0] != 0.0f) == ~0ull);
-  return near;
-}
-
 // Basis and activation of one (point, feature) for the sparse kernels.
 struct Live {
   f32x4 b, d1, d2, d3;   // the 4 live bases and derivatives

@@ -105,9 +105,11 @@ size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
 
 // layers of a layer-level call that the fp16 matrix kernels take (they need the sparse tables as their fallback)
 bool layer_f16(int D, int D2, const pdekan::LayerView& L) {
-  return pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0;
+  return (pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0) || pdekan::f16_jets12_eligible(D, D2, L);
 }
-constexpr size_t kLayerStatWords = 64;   // act / cot / w maxima of a layer-level call, 4 words each (256 bytes)
+// act / cot / w maxima of a layer-level call (256 bytes): a word per jet (4 or 12 used) at kStatAct and kStatCot, one at kStatW
+constexpr size_t kLayerStatWords = 64;
+constexpr int kStatAct = 0, kStatCot = 12, kStatW = 24;
 
 // tables of a layer forward: packed weights (two orders), sparse tables, knot-row classes, fp16 planes and maxima
 size_t layer_fwd_floats(int D, int D2, const pdekan::LayerView& L) {
@@ -137,7 +139,24 @@ struct F16Io {
 // matrix layer above
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
                 float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr, unsigned* act_out = nullptr) {
-  if (h && h->wpl && win) {
+  if (h && h->wpl && D == 6) {
+    // 12 jets: the fp16 matrix kernel on whole groups of 8 points when every knot row is (nearly) equally spaced, else
+    // the streaming kernel (decided on the device); the last n % 8 points always stream
+    const int64_t n8 = n / 8 * 8;
+    const size_t J = 12;
+    if (n8) {
+      {
+        ProfScope ps(st, "L%d.fwd.mfma_f16x2", li);
+        pdekan::launch_fwd12_f16(L, a, h->wpl, y, n8, h->act_in, h->wmax, st);
+      }
+      ProfScope ps(st, "L%d.fwd.stream", li);
+      pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n8, st, true);
+    }
+    if (n > n8) {
+      ProfScope ps(st, "L%d.fwd.stream", li);
+      pdekan::launch_fwd_generic(D, D2, L, a + (size_t)n8 * L.I * J, wt, y + (size_t)n8 * L.O * J, n - n8, st);
+    }
+  } else if (h && h->wpl && win) {
     // both on the same grid: the fp16 matrix kernel runs when every knot row is (nearly) equally spaced, else the
     // sparse kernel does (decided on the device)
     ProfScope ps(st, "L%d.fwd.mfma_f16x2", li);
@@ -305,16 +324,17 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
   return PDEKAN_OK;
 }
 
-// Maxima the fp16 matrix kernels scale their operands by, one 4-word slot each: per layer boundary l = 0 .. nl the
-// per-jet maxima of the jets entering layer l (act) and of the cotangents of those jets (cot), per layer the maximum of
-// its packed weights (w).  act and cot are cleared per micro-batch, w once per call.
+// Maxima the fp16 matrix kernels scale their operands by, one slot of a word per jet (4 or 12 used) each: per layer
+// boundary l = 0 .. nl the per-jet maxima of the jets entering layer l (act) and of the cotangents of those jets (cot),
+// per layer the maximum of its packed weights (w).  act and cot are cleared per micro-batch, w once per call.
 struct ModelStats {
   unsigned* base; int nl;
-  static size_t words(int nl) { return (size_t)12 * (nl + 1); }
-  unsigned* act(int l) const { return base + 4 * l; }
-  unsigned* cot(int l) const { return base + 4 * (nl + 1) + 4 * l; }
-  unsigned* w(int l) const { return base + 8 * (nl + 1) + 4 * l; }
-  size_t per_batch_bytes() const { return (size_t)8 * (nl + 1) * 4; }
+  static constexpr int kSlot = 12;
+  static size_t words(int nl) { return (size_t)(2 * kSlot + 4) * (nl + 1); }
+  unsigned* act(int l) const { return base + kSlot * l; }
+  unsigned* cot(int l) const { return base + kSlot * (nl + 1) + kSlot * l; }
+  unsigned* w(int l) const { return base + 2 * kSlot * (nl + 1) + 4 * l; }
+  size_t per_batch_bytes() const { return (size_t)2 * kSlot * (nl + 1) * 4; }
   size_t bytes() const { return words(nl) * 4; }
 };
 
@@ -350,7 +370,7 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     const size_t wf = win_floats(P.D, P.D2, P.L[l]);
     W.win[l] = wf ? take(wf) : nullptr;
     if (!ws && wf) W.win[l] = reinterpret_cast<float*>(1);   // sizing pass: only the total matters
-    const bool f16 = wf && pdekan::f16_eligible(P.D, P.D2, P.L[l]);
+    const bool f16 = (wf && pdekan::f16_eligible(P.D, P.D2, P.L[l])) || pdekan::f16_jets12_eligible(P.D, P.D2, P.L[l]);
     W.wpl[l] = f16 ? take(pdekan::f16_wplane_floats(P.L[l])) : nullptr;
   }
   for (size_t l = 0; l <= nl; ++l) {
@@ -396,10 +416,11 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
   if (f16) {
     if (!*act_ready) {
       ProfScope ps(st, "L%d.jet_absmax", l);
-      pdekan::launch_jet_absmax(W.act[l], m * P.L[l].I, S.act(l), st);
+      if (P.D == 6) pdekan::launch_jet_absmax12(W.act[l], m * P.L[l].I, S.act(l), st);
+      else pdekan::launch_jet_absmax(W.act[l], m * P.L[l].I, S.act(l), st);
     }
     io.wpl = W.wpl[l]; io.act_in = S.act(l); io.wmax = S.w(l);
-    io.act_out = (l + 1 < nl && W.wpl[l + 1]) ? S.act(l + 1) : nullptr;
+    io.act_out = (P.D == 2 && l + 1 < nl && W.wpl[l + 1]) ? S.act(l + 1) : nullptr;   // (the 12-jet kernel leaves none)
   }
   // a layer the sparse kernel takes can leave the maxima of its outputs for an fp16 matrix layer above as well
   unsigned* sparse_out = nullptr;
@@ -409,7 +430,7 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
 }
 
 // Tables of one layer-level call, carved from the caller's workspace in this order.
-struct LayerTables { float *wp, *wt, *win, *ginfo, *wpl; unsigned* stats; };   // stats: act [0..3], cot [4..7], w [8]
+struct LayerTables { float *wp, *wt, *win, *ginfo, *wpl; unsigned* stats; };   // stats: see kStatAct, kStatCot, kStatW
 
 bool carve_layer(Carver& c, int D, int D2, const pdekan::LayerView& L, bool with_win, LayerTables& T) {
   T.wp = c.take(L.packed_floats());
@@ -431,8 +452,8 @@ int pack_layer(pdekan::LayerView& L, const LayerTables& T, hipStream_t st) {
   if (T.wpl) {
     if (hipMemsetAsync(T.stats, 0, kLayerStatWords * 4, st) != hipSuccess)
       return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
-    pdekan::launch_absmax(T.wp, (int64_t)L.packed_floats(), T.stats + 8, st);
-    pdekan::launch_pack_wplanes16(L, T.wp, T.stats + 8, T.wpl, st);
+    pdekan::launch_absmax(T.wp, (int64_t)L.packed_floats(), T.stats + kStatW, st);
+    pdekan::launch_pack_wplanes16(L, T.wp, T.stats + kStatW, T.wpl, st);
   }
   return PDEKAN_OK;
 }
@@ -454,8 +475,9 @@ int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_je
   if (rc) return rc;
   F16Io io;
   if (T.wpl) {
-    pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats, st);
-    io.wpl = T.wpl; io.act_in = T.stats; io.wmax = T.stats + 8;
+    if (n_dir == 6) pdekan::launch_jet_absmax12(x_jet, n * L.I, T.stats + kStatAct, st);
+    else pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats + kStatAct, st);
+    io.wpl = T.wpl; io.act_in = T.stats + kStatAct; io.wmax = T.stats + kStatW;
   }
   return run_forward(n_dir, n_second, L, x_jet, T.wt, T.win, y_jet, n, st, 0, T.wpl ? &io : nullptr);
 }
@@ -561,13 +583,14 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   rc = pack_layer(L, T, st);
   if (rc) return rc;
   F16Io io;
-  if (T.wpl) {
-    pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats, st);
-    pdekan::launch_jet_absmax(gy_jet, n * L.O, T.stats + 4, st);
-    io.wpl = T.wpl; io.act_in = T.stats; io.cot_in = T.stats + 4; io.wmax = T.stats + 8;
+  const bool f16 = T.wpl && n_dir == 2;
+  if (f16) {
+    pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats + kStatAct, st);
+    pdekan::launch_jet_absmax(gy_jet, n * L.O, T.stats + kStatCot, st);
+    io.wpl = T.wpl; io.act_in = T.stats + kStatAct; io.cot_in = T.stats + kStatCot; io.wmax = T.stats + kStatW;
   }
   return run_backward(n_dir, n_second, L, x_jet, gy_jet, T.wp, T.win, gx_jet, part, grads, accumulate, n, st, 0,
-                      T.wpl ? &io : nullptr);
+                      f16 ? &io : nullptr);
 }
 
 size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers, int64_t n, int32_t n_dir,
@@ -703,7 +726,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
                               m, st, l);
         } else {
           F16Io io;
-          const bool f16 = W.wpl[l] != nullptr;
+          const bool f16 = W.wpl[l] != nullptr && P.D == 2;
           if (f16) {
             // per-jet maxima of the cotangents of this layer's outputs: left by the layer above when it ran on the
             // fp16 matrix kernels too, else measured here
