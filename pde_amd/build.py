@@ -17,6 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdekan.so")
 SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "kan_f16.hip", "pdekan_api.hip"]
+# kan_f16.hip: without the SLP vectorizer.  With it, hipcc 7.2 (-O3, gfx950) builds the 12-jet weight-gradient kernel
+# into code whose expanded columns come out wrong in lanes 48..63 (first element of each packed pair), whatever the
+# source-level form of the expansion; the explicit vector types in the kernels are packed by legalization regardless.
+EXTRA_FLAGS = {"kan_f16.hip": ["-fno-slp-vectorize"]}
 INCLUDE = os.path.join(HERE, "..", "include")
 ARCH = "gfx950"
 
@@ -48,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, s), "-o", obj, "-I", CSRC]
+               os.path.join(CSRC, s), "-o", obj, "-I", CSRC] + EXTRA_FLAGS.get(s, [])
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))

@@ -1364,6 +1364,503 @@ fwd12_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, co
   }
 }
 
+// ---- input-jet gradients, 12 jets: wave = 8 points x 3 groups = 6 row tiles of gY (A operands, in registers) against
+// the W planes of 64 outputs at a time, as in bwd_input_f16_kernel; a stage = 4 features = NB column tiles x 2
+// k-steps = 2*NB regions of 18 matrix instructions.  The stage's gE tile [8 points][4*CP columns][12 slots] is
+// parked in LDS; lane (p = lane & 7, f = (lane >> 3) & 3) pulls the 4 + 1 live columns of its pair and applies the
+// chain rule during the matrix instructions of the next stage (lanes 32..63 repeat lanes 0..31).
+template <int C1, int ACT, bool GEN>
+struct Bwi12 {
+  static constexpr int CP = (C1 + 7) / 8 * 8;
+  static constexpr int NB = CP / 4;
+  static constexpr int NR = 2 * NB;
+  static constexpr int ROW = 4 * CP * 12 + 4;              // words per point in the parked gE tile (+4: bank spread)
+  static constexpr int GROW = 64 * 12 + 4;                 // words per point of the staged raw gY rows
+  static constexpr int TILE = 8 * (ROW > GROW ? ROW : GROW);
+  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int nk = C1 + 3;
+  static constexpr int kStageVecs = 2 * NB * 2 * 64;
+};
+
+struct PairBack12 { Basis bs; Act av; f32x4 x[3]; };
+
+// gradient with respect to the 12 input jets of one pair from the gE jets q of its 4 + 1 live columns, with
+//   E_0 = B,  E_{1+k} = B' a_{1+k},  E_{7+k} = B'' a_{1+k}^2 + B' a_{7+k}:
+//   d/da_0     = sum_m q_0 B' + (sum_k q_{1+k} a_{1+k} + q_{7+k} a_{7+k}) B'' + (sum_k q_{7+k} a_{1+k}^2) B'''
+//   d/da_{1+k} = sum_m q_{1+k} B' + 2 a_{1+k} q_{7+k} B''          d/da_{7+k} = sum_m q_{7+k} B'
+// inv[j] takes the scales of slot j out of q.
+__device__ __forceinline__ void chain_rule12(const PairBack12& pb, const f32x4 (&dcol)[5][3], const float (&inv)[12],
+                                             f32x4 (&out)[3]) {
+  float U1[12], U2[12], U3[5];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { U1[j] = 0.f; U2[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) U3[k] = 0.f;
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const float e1 = m < 4 ? pb.bs.d1[m & 3] : pb.av.f1;
+    const float e2 = m < 4 ? pb.bs.d2[m & 3] : pb.av.f2;
+    const float e3 = m < 4 ? pb.bs.d3[m & 3] : pb.av.f3;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const float q = dcol[m][j >> 2][j & 3];
+      U1[j] += q * e1;
+      if (j >= 1) U2[j] += q * e2;
+      if (j >= 7) U3[j - 7] += q * e3;
+    }
+  }
+  float a[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { a[j] = pb.x[j >> 2][j & 3]; U1[j] *= inv[j]; U2[j] *= inv[j]; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) U3[k] *= inv[7 + k];
+  float o[12];
+  o[0] = U1[0];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[0] += a[1 + k] * U2[1 + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) o[0] += a[7 + k] * U2[7 + k] + a[1 + k] * a[1 + k] * U3[k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { o[1 + k] = U1[1 + k] + 2.0f * a[1 + k] * U2[7 + k]; o[7 + k] = U1[7 + k]; }
+  o[6] = U1[6];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) out[j >> 2][j & 3] = o[j];
+}
+
+// N must be a multiple of 8.  cot_in: per-slot maxima of gy (12 words).
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                       const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
+                       int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax) {
+  using F = Bwi12<C1, ACT, GEN>;
+  constexpr int NB = F::NB, NR = F::NR, KP = F::KP, nk = F::nk, CP = F::CP, ROW = F::ROW, GROW = F::GROW;
+  constexpr int C = C1 - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  {
+    bool near = true, equal = true;
+    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+      const float gi = ginfo[i < I ? i : 0];
+      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+    }
+    if (!near || equal == GEN) return;
+  }
+  float* sK = reinterpret_cast<float*>(smem);
+  float* sD = sK + I * KP + wave * F::TILE;
+  if constexpr (GEN) {
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  float inv[12];
+  const int r = lane & 15, kb = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) & 3;
+  float my_t[3];                              // this lane's A-operand rows: slot 4g + (r & 3) of point (r >> 2) of the row tile
+  {
+    const float sw = pow2_scale(__uint_as_float(wmax[0]));
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const float t = pow2_scale(__uint_as_float(cot_in[j]));
+      inv[j] = rcp_pow2(t * sw);
+      if ((j & 3) == (r & 3)) my_t[j >> 2] = t;
+    }
+  }
+  __syncthreads();
+
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 8;
+  if (P0 >= N) return;                        // wave-uniform; no barrier below
+  const int nst = I / 4;
+  const int64_t prow = P0 + p_local;
+  const char* xrow = reinterpret_cast<const char*>(a + (prow * I + f_local) * 3);
+  f32x4* orow = ga + (prow * I + f_local) * 3;
+  constexpr int kStageBytes = 4 * 48, kStageVec = 12;       // 4 features x 12 floats
+  const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
+  const int npass = O / 64;
+
+  for (int ob = 0; ob < npass; ++ob) {
+    // ---- the wave's gY rows of this output block -> A operands in registers ----
+    u32x4 GAh[6][2], GAl[6][2];
+    {
+      f32x4 graw[8][3];
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) graw[v][g] = gy[((P0 + v) * O + ob * 64 + lane) * 3 + g];
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(sD + v * GROW + lane * 12 + 4 * g) = graw[v][g];
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int g = mt >> 1, pq = mt & 1;
+          const float* src = sD + (4 * pq + (r >> 2)) * GROW + (32 * ks + 8 * kb) * 12 + 4 * g + (r & 3);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = src[e * 12] * my_t[g];
+          unsigned h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair16(v[2 * e], v[2 * e + 1], h[e], l[e]);
+          GAh[mt][ks] = (u32x4){h[0], h[1], h[2], h[3]};
+          GAl[mt][ks] = (u32x4){l[0], l[1], l[2], l[3]};
+        }
+    }
+    const u32x4* wbase = wpl + (size_t)ob * nst * F::kStageVecs;
+    WTile16 Wt[4];
+    auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
+    fetch_w(Wt[0], wbase);
+    fetch_w(Wt[1], wbase + 128);
+
+    f32x4 acc[6][NB];
+    PairBack12 prev, cur;
+    f32x4 dcol[5][3];
+    f32x4 old[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (ob > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) old[g] = orow[g];
+    }
+    prev.av = Act{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) prev.bs.d1[m] = prev.bs.d2[m] = prev.bs.d3[m] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) dcol[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 xnext[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      prev.x[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cur.x[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+      xnext[g] = *reinterpret_cast<const f32x4*>(xrow + (nst > 1 ? kStageBytes : 0) + 16 * g);
+    }
+
+    for (int s = 0; s < nst; ++s) {
+      const u32x4* wsrc = wbase + (size_t)s * F::kStageVecs;
+      const u32x4* wnxt = wbase + (size_t)((s + 1 < nst) ? s + 1 : 0) * F::kStageVecs;
+      f32x4* odst = orow + (s > 0 ? s - 1 : 0) * kStageVec;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int ks = i / NB, n = i % NB;
+        {
+          const int t = i + 2;
+          fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
+        }
+        if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
+          f32x4 out[3];
+          chain_rule12(prev, dcol, inv, out);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) odst[g] = out[g] + old[g];
+        }
+        if (i == 1) {                         // this stage's pair: basis, activation (kept for the next stage)
+          const float* kn = kbase + 4 * s * KP;
+          const FeatGrid fg = {kn[0], kn[nk - 1], fabsf(kn[GEN ? nk + 4 : nk])};
+          eval_pair_d3<ACT, GEN>(kn, nk, fg, cur.x[0][0], cur.bs, cur.av);
+          if (ob > 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) old[g] = orow[s * kStageVec + g];
+          }
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h),
+                                                             ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
+                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
+        if (i == 0) interleave<18, 14>(); else if (i == 1) interleave<18, 9>(); else interleave<18, 2>();
+        PDEKAN_REGION_FENCE();
+      }
+      // park the stage's gE tile: lane (c = r, q = kb) holds slots 4g .. 4g+3 of point 4pq + q, column 16n + c
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * n + r) * 12 + 4 * (m >> 1)) = acc[m][n];
+      const float* drow = sD + p_local * ROW + (f_local * CP) * 12;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = cur.bs.c0 + m;
+        const bool ok = (c >= 0) & (c < C);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(drow + (ok ? c : C) * 12 + 4 * g);
+          dcol[m][g] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) dcol[4][g] = *reinterpret_cast<const f32x4*>(drow + C * 12 + 4 * g);
+      prev = cur;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        cur.x[g] = xnext[g];
+        xnext[g] = *reinterpret_cast<const f32x4*>(xrow + (size_t)((s + 2 < nst) ? s + 2 : 0) * kStageBytes + 16 * g);
+      }
+    }
+    {                                           // chain rule of the last stage
+      f32x4 out[3];
+      chain_rule12(prev, dcol, inv, out);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) orow[(nst - 1) * kStageVec + g] = out[g] + old[g];
+    }
+  }
+}
+
+// ---- weight gradients, 12 jets: the kernel above over virtual points.  A block of 8 points is three steps, one per
+// group; step (b, g) multiplies the E tile [columns][8 points x 4 rows of group g] with the gY rows of the same 8
+// points and group (K = 32).  The basis of a pair is evaluated once per block (with group 0) and kept for the other
+// two groups, whose columns differ only in the row coefficients.  Scales: gY's slot j by t_j, E's by c / t_j.
+// Runs when every knot row of the layer is (nearly) equally spaced; a block takes the variant that matches its own
+// features' rows.  chunk_pts and N are multiples of 16.
+constexpr int kF16FlushPoints12 = 160;       // 60 chained steps per accumulator between flushes (512 / 8 = 64 above)
+
+struct PairKeep12 { Basis bs; Act av; };
+
+// columns of group GRP of one pair, scaled
+template <int GRP>
+__device__ __forceinline__ void expand_group12(const PairKeep12& pk, const f32x4 (&x)[3], const SlotScales12& sc, PairCols& out) {
+  const RowCoefs12 rc = row_coefs12(x, sc);
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const float b0 = m < 4 ? pk.bs.b[m & 3] : pk.av.f0, b1 = m < 4 ? pk.bs.d1[m & 3] : pk.av.f1;
+    const float b2 = m < 4 ? pk.bs.d2[m & 3] : pk.av.f2;
+    if (GRP == 0) { out.col[m] = rc.be[0] * b1; out.col[m][0] = rc.s0 * b0; }
+    if (GRP == 1) { out.col[m] = rc.be[1] * b1; out.col[m][3] += rc.ga[1][3] * b2; }
+    if (GRP == 2) out.col[m] = rc.be[2] * b1 + rc.ga[2] * b2;
+  }
+  out.c0 = pk.bs.c0;
+}
+
+template <int ACT, bool GEN>
+__device__ __forceinline__ void eval_keep12(const float* knots, int nk, const FeatGrid& fg, float x, PairKeep12& pk) {
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, x, pk.bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, x, pk.bs);
+  pk.av = eval_act(ACT, x);
+}
+
+// One step.  GN = the group of the step being prepared (s+1).  graw holds the raw gY rows of step s+1 on entry,
+// xnext the jets of the pairs of the block after the one in xcur.  Region plan as in wg16_step; with GN == 0 the
+// pairs of the next block move in (xcur <- xnext, basis evaluated) and the block after it is fetched from xrow2.
+
+template <int C1, int FE, int ACT, bool GEN, int GN>
+__device__ __forceinline__ void wg12_step(f32x4 (&acc)[FE * C1 / 16][4], const GyPlanes16& G, GyPlanes16& Gn, TileOps16& cur,
+                                          f32x4 (&graw)[4][2], f32x4 (&xcur)[3], f32x4 (&xnext)[3], PairKeep12& pk,
+                                          unsigned* sE, const float* knots, const FeatGrid& fg, const SlotScales12& se,
+                                          const f32x4& tg, int& prev_c0, const char* __restrict__ xrow2,
+                                          const char* __restrict__ grow1, const char* __restrict__ grow2, unsigned xoff,
+                                          unsigned goff, int lane, int O) {
+  constexpr int COLS = FE * C1, NT = COLS / 16, nk = C1 + 3;
+  static_assert(NT == 6 || NT == 7, "the region plan below is written for 6 or 7 column tiles");
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
+  const unsigned* esrc = sE + r * kWgRw + q * 4;
+  PairCols pj;
+  Planes16 pp[5];
+  TileOps16 last;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    TileOps16 nxt;
+    if (t + 1 < NT - 1) nxt = read_wg_tile<COLS>(esrc, t + 1);
+    if (t == NT - 3) last = read_wg_tile<COLS>(esrc, NT - 1);
+    if (t == NT - 2) nxt = last;
+    if (t == 0) {
+      if (GN == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xcur[g] = xnext[g];
+        eval_keep12<ACT, GEN>(knots, nk, fg, xcur[0][0], pk);
+      }
+      expand_group12<GN>(pk, xcur, se, pj);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) graw[3][e] = ld16v(grow1, goff + (unsigned)(e * O + 3 * 16) * 48u);
+    }
+    if (t == 1) {
+      if (GN == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xnext[g] = ld16v(xrow2, xoff + 16u * g);
+      }
+      pp[0] = split_jet16(pj.col[0]); pp[1] = split_jet16(pj.col[1]); pp[2] = split_jet16(pj.col[2]);
+    }
+    if (t == 2) { pp[3] = split_jet16(pj.col[3]); pp[4] = split_jet16(pj.col[4]); }
+    if (t >= NT - 4) split_gy_tile16(graw[t - (NT - 4)], tg, Gn, t - (NT - 4));
+    if (t >= NT - 3) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        graw[t - (NT - 3)][e] = ld16v(grow2, goff + (unsigned)(e * O + (t - (NT - 3)) * 16) * 48u);
+    }
+    if (t == NT - 3) {
+      unsigned* base = sE + (f_local * C1) * kWgRw + p_local * 2;
+      park_wg16<C1, COLS>(base, sE + (f_local * C1) * kWgRw + 16, pp, pj.c0, prev_c0);
+    }
+    if (t == NT - 1) nxt = read_wg_tile<COLS>(esrc, 0);
+    mfma_wg_tile(acc[t], cur, G);
+    cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int C1, int FE, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+bwd_weight12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                        const float* __restrict__ ginfo, float* __restrict__ part, int64_t N, int I, int O,
+                        int64_t chunk_pts, int nx, int ny, int nz, const unsigned* __restrict__ act_in,
+                        const unsigned* __restrict__ cot_in) {
+  constexpr int COLS = FE * C1, NT = COLS / 16, nk = C1 + 3;
+  static_assert(COLS % 16 == 0 && (FE == 8 || FE == 4), "16-wide column tiles; 8 points x FE features per step");
+  constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  constexpr int kWaveWords = 2 * COLS * kWgRw + FE * KP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bx, by, bz;
+  {
+    const int b = blockIdx.x;
+    if (nz % 8 == 0) {
+      const int rr = b >> 3;
+      bx = rr % nx; by = (rr / nx) % ny; bz = (rr / (nx * ny)) * 8 + (b & 7);
+    } else {
+      bx = b % nx; by = (b / nx) % ny; bz = b / (nx * ny);
+    }
+  }
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (!all_rows_near_uniform(ginfo, I)) return;         // the split passes of the 4-jet kernels do the layer
+  {
+    const float gi = ginfo[bx * 4 * FE + lane % (4 * FE)];
+    const bool all_equal = __builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull;
+    if (all_equal == GEN) return;
+  }
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;
+  float* sK = reinterpret_cast<float*>(sE + 2 * COLS * kWgRw);
+  const int r = lane & 15, q = lane >> 4, p_local = lane & 7, f_local = (lane >> 3) % FE;
+  const int i0 = (bx * 4 + wave) * FE, o0 = by * 64;
+  if constexpr (GEN) {
+    for (int idx = lane; idx < FE * KP; idx += 64) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = grid[(size_t)(i0 + f) * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = lane; idx < FE * (nk + 1); idx += 64) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)(i0 + f) * nk + k] : ginfo[i0 + f];
+    }
+  }
+  for (int idx = lane; idx < 2 * COLS * kWgRw; idx += 64) sE[idx] = 0u;
+  const float* knots = sK + f_local * KP + (GEN ? 3 : 0);
+  const FeatGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
+                       fabsf(ginfo[i0 + f_local])};
+  SlotScales12 se;
+  f32x4 tg[3];
+  float inv_c;
+  {
+    const SlotScales12 eb = expanded_slot_scales12(act_in, max_inv_h(ginfo, I, lane));
+    float c = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      tg[j >> 2][j & 3] = pow2_scale(__uint_as_float(cot_in[j]));
+      c = fminf(c, eb.s[j] * tg[j >> 2][j & 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) se.s[j] = c * rcp_pow2(tg[j >> 2][j & 3]);
+    inv_c = rcp_pow2(c);
+  }
+
+  f32x4 acc[NT][4], tot[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  const int64_t pbeg = (int64_t)bz * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  const char* xb = reinterpret_cast<const char*>(a);
+  const char* gb = reinterpret_cast<const char*>(gy);
+  const unsigned xoff = (unsigned)(p_local * I + i0 + f_local) * 48u;
+  const unsigned goff = (unsigned)(2 * q * O + o0 + r) * 48u;
+  const size_t xstride = (size_t)I * 48, gstride = (size_t)O * 48;       // bytes per point
+
+  if (pbeg < pend) {
+    f32x4 graw[4][2], xcur[3], xnext[3];
+    GyPlanes16 GA, GB;
+    PairKeep12 pk;
+    int prev_c0 = -100;
+    {
+      f32x4 g0[4][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          g0[m][e] = ld16v(gb + pbeg * gstride, goff + (unsigned)(e * O + m * 16) * 48u);
+          graw[m][e] = ld16v(gb + pbeg * gstride + 16, goff + (unsigned)(e * O + m * 16) * 48u);
+        }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        xcur[g] = ld16v(xb + pbeg * xstride, xoff + 16u * g);
+        xnext[g] = ld16v(xb + (pbeg + 8) * xstride, xoff + 16u * g);
+      }
+      PairCols pj;
+      Planes16 pp[5];
+      eval_keep12<ACT, GEN>(knots, nk, fg, xcur[0][0], pk);
+      expand_group12<0>(pk, xcur, se, pj);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) pp[m] = split_jet16(pj.col[m]);
+      unsigned* base = sE + (f_local * C1) * kWgRw + p_local * 2;
+      park_wg16<C1, COLS>(base, sE + (f_local * C1) * kWgRw + 16, pp, pj.c0, prev_c0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) split_gy_tile16(g0[m], tg[0], GA, m);
+    }
+    TileOps16 cur = read_wg_tile<COLS>(sE + r * kWgRw + q * 4, 0);
+    for (int64_t pb = pbeg; pb < pend;) {
+      const int64_t pstop = (pb + kF16FlushPoints12 < pend) ? pb + kF16FlushPoints12 : pend;
+      for (; pb < pstop; pb += 16) {
+        // past the end of the chunk: any valid rows, fetched (and expanded) but never used
+        const int64_t p1 = pb + 8, p2 = (pb + 16 < pend) ? pb + 16 : pbeg, p3 = (pb + 24 < pend) ? pb + 24 : pbeg;
+        const char* gA = gb + pb * gstride;     // gY rows of the four blocks around: this, next, the two after
+        const char* gB = gb + p1 * gstride;
+        const char* gC = gb + p2 * gstride;
+        // step (pb, 0): prepares (pb, 1), fetches gY of (pb, 2)
+        wg12_step<C1, FE, ACT, GEN, 1>(acc, GA, GB, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[1], prev_c0, xb,
+                                       gA + 16, gA + 32, xoff, goff, lane, O);
+        // step (pb, 1): prepares (pb, 2), fetches gY of (p1, 0)
+        wg12_step<C1, FE, ACT, GEN, 2>(acc, GB, GA, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[2], prev_c0, xb,
+                                       gA + 32, gB, xoff, goff, lane, O);
+        // step (pb, 2): prepares (p1, 0) (its jets are in xnext), fetches the jets of p2 and gY of (p1, 1)
+        wg12_step<C1, FE, ACT, GEN, 0>(acc, GA, GB, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[0], prev_c0,
+                                       xb + p2 * xstride, gB, gB + 16, xoff, goff, lane, O);
+        wg12_step<C1, FE, ACT, GEN, 1>(acc, GB, GA, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[1], prev_c0, xb,
+                                       gB + 16, gB + 32, xoff, goff, lane, O);
+        wg12_step<C1, FE, ACT, GEN, 2>(acc, GA, GB, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[2], prev_c0, xb,
+                                       gB + 32, gC, xoff, goff, lane, O);
+        wg12_step<C1, FE, ACT, GEN, 0>(acc, GB, GA, cur, graw, xcur, xnext, pk, sE, knots, fg, se, tg[0], prev_c0,
+                                       xb + p3 * xstride, gC, gC + 16, xoff, goff, lane, O);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          tot[t][m] += acc[t][m];
+          acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float* dst = part + (((size_t)bz * O + o0 + m * 16 + r) * I + i0) * C1 + t * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(dst) = tot[t][m] * inv_c;
+    }
+}
+
 // ==========================================================================================================
 // host side
 // ==========================================================================================================
@@ -1383,7 +1880,7 @@ bool f16_eligible(int D, int D2, const LayerView& L) {
 bool f16_jets12_eligible(int D, int D2, const LayerView& L) {
   if (D != 6 || D2 != 5 || f16_disabled()) return false;
   if (L.G != 10) return false;                       // one wave's E tile of a grid-20 layer does not fit beside three others
-  return L.I >= 8 && L.I % 8 == 0 && L.I <= 256 && L.O % 64 == 0 && L.O <= 256;
+  return L.I >= 32 && L.I % 32 == 0 && L.I <= 256 && L.O % 64 == 0 && L.O <= 256;   // (32: features per weight-gradient block)
 }
 
 static int cp_of(const LayerView& L) { return (L.C1() + 7) / 8 * 8; }
@@ -1488,6 +1985,32 @@ void launch_fwd12_f16(const LayerView& L, const float* a, const float* wpl, floa
   }
 }
 
+template <int ACT, bool GEN>
+static void bwi12_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
+                         const unsigned* cot_in, const unsigned* wmax, hipStream_t st) {
+  using F = Bwi12<14, ACT, GEN>;
+  auto k = bwd_input12_f16_kernel<14, ACT, GEN>;
+  const size_t lds = ((size_t)L.I * F::KP + 4 * F::TILE) * 4;
+  allow_lds(k, lds);
+  k<<<(unsigned)((N + 31) / 32), 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(gy),
+                                                 L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wplb),
+                                                 reinterpret_cast<f32x4*>(ga), N, L.I, L.O, cot_in, wmax);
+}
+
+// 12-jet input gradients (f16_jets12_eligible layers): cot_in = per-slot maxima of gy (12 words).  N must be a
+// multiple of 8.
+void launch_bwd_input12_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
+                            const unsigned* cot_in, const unsigned* wmax, hipStream_t st) {
+  const float* wplb = wpl + f16_wplane_floats(L) / 2;
+  if (L.act == kActSiLU) {
+    bwi12_launch<kActSiLU, false>(L, a, gy, wplb, ga, N, cot_in, wmax, st);
+    bwi12_launch<kActSiLU, true>(L, a, gy, wplb, ga, N, cot_in, wmax, st);
+  } else {
+    bwi12_launch<kActIdentity, false>(L, a, gy, wplb, ga, N, cot_in, wmax, st);
+    bwi12_launch<kActIdentity, true>(L, a, gy, wplb, ga, N, cot_in, wmax, st);
+  }
+}
+
 template <int C1, int ACT, bool GEN>
 static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                            const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
@@ -1548,6 +2071,27 @@ void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const floa
                                   const unsigned* cot_in, hipStream_t st) {
   if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
   else bww_f16_launch<24, 4>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
+}
+
+// 12-jet weight gradients on the grid of launch_bwd_weight_f16_blocks (grid 10); act_in / cot_in: per-slot maxima of a
+// and gy (12 words each).  Writes nothing unless every knot row of the layer is (nearly) equally spaced.
+void launch_bwd_weight12_f16(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16, int64_t chunk,
+                             int nx, int ny, int nmain, const unsigned* act_in, const unsigned* cot_in, hipStream_t st) {
+  constexpr int C1 = 14, FE = 8;
+  auto kb = (L.act == kActSiLU) ? bwd_weight12_f16_kernel<C1, FE, kActSiLU, false>
+                                : bwd_weight12_f16_kernel<C1, FE, kActIdentity, false>;
+  auto kg = (L.act == kActSiLU) ? bwd_weight12_f16_kernel<C1, FE, kActSiLU, true>
+                                : bwd_weight12_f16_kernel<C1, FE, kActIdentity, true>;
+  const size_t lds_b = (size_t)4 * (2 * FE * C1 * kWgRw + FE * kKnotPadU) * 4;
+  const size_t lds_g = (size_t)4 * (2 * FE * C1 * kWgRw + FE * kKnotPadN) * 4;
+  allow_lds(kb, lds_b);
+  allow_lds(kg, lds_g);
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
+  kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
 }
 
 }  // namespace pdekan

@@ -353,8 +353,13 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
 constexpr int kSumWaves = 16;
 
 __global__ void __launch_bounds__(64 * kSumWaves)
-sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, float* __restrict__ out) {
+sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, float* __restrict__ out, ChunkSelect sel) {
   __shared__ float s_r[kSumWaves][64];
+  if (sel.ginfo) {                            // which run of chunks holds this call's partials: settled by the knot rows
+    const bool u = all_rows_near_uniform(sel.ginfo, sel.I);
+    part += (size_t)(u ? sel.first_uniform : sel.first_other) * total;
+    nchunks = u ? sel.n_uniform : sel.n_other;
+  }
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + lane;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -695,12 +700,12 @@ bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a
 }
 
 void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
-                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st) {
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel) {
   const int edges = L.O * L.I;
   const float* src = part;
-  if (nchunks > 1) {
+  if (nchunks > 1 || sel.ginfo) {
     const size_t total = L.packed_floats();
-    sum_partials_kernel<<<(unsigned)((total + 63) / 64), 64 * kSumWaves, 0, st>>>(part, nchunks, total, sum_buf);
+    sum_partials_kernel<<<(unsigned)((total + 63) / 64), 64 * kSumWaves, 0, st>>>(part, nchunks, total, sum_buf, sel);
     src = sum_buf;
   }
   const int blocks = (edges + 127) / 128;

@@ -24,6 +24,8 @@ struct LayerView {
 // spaced (settled on the device from the layer's ginfo): with ginfo set, the kernel returns at once in that case.
 struct JetSkip { const float* ginfo = nullptr; int I = 0; };
 
+struct ChunkSelect { const float* ginfo = nullptr; int I = 0, first_uniform = 0, n_uniform = 0, first_other = 0, n_other = 0; };
+
 // kan_kernels.hip
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st);
 // out[N][I][G+3] = order-th derivative of every cubic basis at x[N][I]
@@ -43,9 +45,11 @@ bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a,
 int generic_weight_chunks(int64_t N, int I, int O);
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
                                int nchunks, int64_t N, hipStream_t st);
-// sum_buf: packed_floats() floats of scratch, used when nchunks > 1
+// sum_buf: packed_floats() floats of scratch, used when nchunks > 1 or with sel
+// sel.ginfo given: the chunks summed are [first_uniform, + n_uniform) when every knot row of the layer is (nearly)
+// equally spaced, else [first_other, + n_other) - settled on the device (nchunks is not used then)
 void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
-                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st);
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel = {});
 bool launch_bs_residual(int D, const float* x, int64_t stride_n, int64_t stride_d, const float* vjet,
                         const float* target, float sigma, float rate, float inv_n, float* res, float* gy,
                         float* loss_part, int nblocks, int64_t N, hipStream_t st);
@@ -94,6 +98,10 @@ bool f16_jets12_eligible(int D, int D2, const LayerView& L);
 void launch_jet_absmax12(const float* t, int64_t elems, unsigned* out12, hipStream_t st);   // per-slot maxima of [elems][12]
 void launch_fwd12_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
                       const unsigned* wmax, hipStream_t st);
+void launch_bwd_input12_f16(const LayerView& L, const float* a, const float* gy, const float* wpl, float* ga, int64_t N,
+                            const unsigned* cot_in, const unsigned* wmax, hipStream_t st);
+void launch_bwd_weight12_f16(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16, int64_t chunk,
+                             int nx, int ny, int nmain, const unsigned* act_in, const unsigned* cot_in, hipStream_t st);
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);
@@ -108,9 +116,10 @@ void launch_bwd_input_mfma(const LayerView& L, const float* a, const float* gy, 
 // with_bf16x3: feature blocks with equally spaced knots go to the split-bf16 kernel, the rest stay fp32
 bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N);
 // act_in / cot_in (per-jet maxima of a and gy, 4 words each) given: the fp16 two-piece kernel instead of the split-bf16 one
+// skip_layer (fp32 kernel only): write nothing when every knot row of the layer is (nearly) equally spaced
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
                             int64_t N, hipStream_t st, bool with_bf16x3 = false, const unsigned* act_in = nullptr,
-                            const unsigned* cot_in = nullptr);
+                            const unsigned* cot_in = nullptr, bool skip_layer = false);
 void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16,
                                   int64_t chunk, int nx, int ny, int nmain, const unsigned* act_in,
                                   const unsigned* cot_in, hipStream_t st);

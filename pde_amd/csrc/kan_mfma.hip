@@ -257,7 +257,8 @@ bwd_weight_mfma_kernel(const float4* __restrict__ a, const float4* __restrict__ 
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // blocks whose features all have (nearly) equally spaced knots belong to bwd_weight_bf16x3_kernel when it runs too
-  if (skip_uniform && __builtin_amdgcn_ballot_w64(ginfo[bx * 4 * KIW + lane % (4 * KIW)] != 0.0f) == ~0ull) return;
+  if (skip_uniform == 1 && __builtin_amdgcn_ballot_w64(ginfo[bx * 4 * KIW + lane % (4 * KIW)] != 0.0f) == ~0ull) return;
+  if (skip_uniform == 2 && all_rows_near_uniform(ginfo, I)) return;      // a 12-jet matrix kernel does the whole layer
   const int p_local = lane % PB, f_local = lane / PB;
   const bool gen_lane = f_local < KIW;
   const int i0 = (bx * 4 + wave) * KIW;
@@ -1079,7 +1080,7 @@ bool bf16x3_weight_eligible(int D, int D2, const LayerView& L, int64_t N) {
 template <int C1, int KIW, int PB>
 static void bww_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
                        hipStream_t st, bool with_bf16x3 = false, const unsigned* act_in = nullptr,
-                       const unsigned* cot_in = nullptr) {
+                       const unsigned* cot_in = nullptr, bool skip_layer = false) {
   constexpr int COLS = KIW * C1, ROWS = PB * 4, RS = ROWS + 4;
   const size_t lds = (size_t)(4 * COLS * RS + ROWS * 80 + 4 * KIW * kKnotPad) * 4;
   auto k = bwd_weight_mfma_kernel<C1, KIW, PB>;
@@ -1091,7 +1092,7 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
     int64_t chunk = (N + nchunks - 1) / nchunks;
     chunk = (chunk + PB - 1) / PB * PB;
     k<<<(unsigned)(nx * ny * nchunks), 256, lds, st>>>(a4, g4, L.grid, L.ginfo, part, N, L.I, L.O, L.act, chunk, nx, ny,
-                                                       nchunks, 0);
+                                                       nchunks, skip_layer ? 2 : 0);
     return;
   }
   if constexpr (C1 % 2 == 0 && (KIW == 8 || KIW == 4) && PB == 8) {
@@ -1125,9 +1126,10 @@ static void bww_launch(const LayerView& L, const float* a, const float* gy, floa
 }
 
 void launch_bwd_weight_mfma(const LayerView& L, const float* a, const float* gy, float* part, int nchunks, int64_t N,
-                            hipStream_t st, bool with_bf16x3, const unsigned* act_in, const unsigned* cot_in) {
-  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in);
-  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in);
+                            hipStream_t st, bool with_bf16x3, const unsigned* act_in, const unsigned* cot_in,
+                            bool skip_layer) {
+  if (L.G == 10) bww_launch<14, 8, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in, skip_layer);
+  else if (L.G == 20) bww_launch<24, 4, 8>(L, a, gy, part, nchunks, N, st, with_bf16x3, act_in, cot_in, skip_layer);
   else bww_launch<9, 16, 4>(L, a, gy, part, nchunks, N, st);
 }
 

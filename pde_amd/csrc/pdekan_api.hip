@@ -105,7 +105,7 @@ size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
 
 // layers of a layer-level call that the fp16 matrix kernels take (they need the sparse tables as their fallback)
 bool layer_f16(int D, int D2, const pdekan::LayerView& L) {
-  return (pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0) || pdekan::f16_jets12_eligible(D, D2, L);
+  return (pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0) || pdekan::f16_jets12_eligible(D, D2, L);   // (12 jets: forward only)
 }
 // act / cot / w maxima of a layer-level call (256 bytes): a word per jet (4 or 12 used) at kStatAct and kStatCot, one at kStatW
 constexpr size_t kLayerStatWords = 64;
@@ -282,6 +282,79 @@ int run_backward_split(const pdekan::LayerView& L, const float* a, const float* 
   return check_launch("layer backward (split passes)");
 }
 
+// 12-jet layers the fp16 matrix kernels take in the fused step: with the split passes (and the sparse input-gradient
+// kernel under them) as what runs instead when some knot row is not (nearly) equally spaced
+bool jets12_f16(int D, int D2, const pdekan::LayerView& L) {
+  return pdekan::f16_jets12_eligible(D, D2, L) && split_jets(D, D2) && pdekan::mfma_eligible(2, 1, L) &&
+         pdekan::sparse_input_grad_eligible(2, 1, L);
+}
+
+// chunks of partial weight gradients of such a layer on n points: [matrix kernel: nch][last n % 16 points: 1]
+// [split passes: 5 * nch] and one chunk of scratch for the sum
+size_t jets12_part_chunks(const pdekan::LayerView& L, int64_t n) {
+  const int64_t n16 = n / 16 * 16;
+  const int nch = n16 ? pdekan::mfma_weight_chunks(n16, L) : 0;
+  return (size_t)nch * (1 + kSplitPasses) + 2;
+}
+
+// Backward of a 12-jet layer for which jets12_f16() holds.  Points [0, n16): the fp16 matrix kernels when every knot
+// row is (nearly) equally spaced, else the split passes - both are launched, the device settles which one works, and
+// the reduction sums the chunks of the one that did.  The last n % 16 points take the streaming kernels.
+// h: W planes and the per-slot maxima of a and gy (12 words each).
+int run_backward_jets12(const pdekan::LayerView& L, const float* a, const float* gy, const float* wp, const float* win,
+                        float* ga, float* const* view, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
+                        hipStream_t st, int li, const F16Io* h) {
+  if (g && (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler)))
+    return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
+  const size_t J = 12, pf = L.packed_floats();
+  const int64_t n16 = n / 16 * 16, tail = n - n16;
+  const int nch = n16 ? pdekan::mfma_weight_chunks(n16, L) : 0;
+  const pdekan::JetSkip skip = {L.ginfo, L.I};
+  float* part_tail = part + (size_t)nch * pf;
+  float* part_split = part_tail + pf;
+  if (n16) {
+    if (g) {
+      ProfScope ps(st, "L%d.bwd_weight.mfma_f16x2", li);
+      int64_t chunk = (n16 + nch - 1) / nch;
+      chunk = (chunk + 15) / 16 * 16;
+      pdekan::launch_bwd_weight12_f16(L, a, gy, part, n16, chunk, L.I / 32, L.O / 64, nch, h->act_in, h->cot_in, st);
+    }
+    if (ga) {
+      ProfScope ps(st, "L%d.bwd_input.mfma_f16x2", li);
+      pdekan::launch_bwd_input12_f16(L, a, gy, h->wpl, ga, n16, h->cot_in, h->wmax, st);
+    }
+    ProfScope ps(st, "L%d.split_passes", li);
+    for (int k = 0; k < kSplitPasses; ++k) {
+      pdekan::launch_gather_jets4(a, view[0], n16 * L.I, k, true, st, skip);
+      pdekan::launch_gather_jets4(gy, view[1], n16 * L.O, k, k == 0, st, skip);
+      if (g)
+        pdekan::launch_bwd_weight_mfma(L, view[0], view[1], part_split + (size_t)k * nch * pf, nch, n16, st, false, nullptr,
+                                       nullptr, true);
+      if (ga) {
+        pdekan::launch_bwd_input_sparse(L, view[0], view[1], win, view[2], n16, st, true);
+        pdekan::launch_scatter_jets4(view[2], ga, n16 * L.I, k, st, skip);
+      }
+    }
+  }
+  if (tail) {
+    ProfScope ps(st, "L%d.bwd.stream", li);
+    const float* at = a + (size_t)n16 * L.I * J;
+    const float* gt = gy + (size_t)n16 * L.O * J;
+    if (g) pdekan::launch_bwd_weight_generic(6, 5, L, at, gt, part_tail, 1, tail, st);
+    if (ga) pdekan::launch_bwd_input_generic(6, 5, L, at, gt, wp, ga + (size_t)n16 * L.I * J, tail, st);
+  }
+  if (g) {
+    ProfScope ps(st, "L%d.reduce_unpack", li);
+    const int t = tail ? 1 : 0;
+    pdekan::ChunkSelect sel = {L.ginfo, L.I, 0, nch + t, tail ? nch : nch + 1, t + kSplitPasses * nch};
+    if (!n16) sel = {L.ginfo, L.I, nch, 1, nch, 1};
+    float* sum_buf = part + (jets12_part_chunks(L, n) - 1) * pf;
+    pdekan::launch_reduce_unpack(L, part, 0, sum_buf, g->base_weight, g->spline_weight, L.scaler ? g->spline_scaler : nullptr,
+                                 accumulate, st, sel);
+  }
+  return check_launch("layer backward (12 jets)");
+}
+
 struct ModelPlan {
   std::vector<pdekan::LayerView> L;
   int D, D2, J;
@@ -309,6 +382,11 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
     if (split_weight_eligible(D, D2, P.L[l], P.mb)) {
       const size_t ps = (size_t)(kSplitPasses * pdekan::mfma_weight_chunks(P.mb, P.L[l]) + 1) * P.L[l].packed_floats();
       if (ps > pf) pf = ps;                  // a last micro-batch under 16 points takes the streaming kernel
+      P.view_floats = 1;
+    }
+    if (jets12_f16(D, D2, P.L[l])) {
+      const size_t ps = jets12_part_chunks(P.L[l], P.mb) * P.L[l].packed_floats();
+      if (ps > pf) pf = ps;
       P.view_floats = 1;
     }
     if (pf > P.part_floats) P.part_floats = pf;
@@ -370,7 +448,7 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
     const size_t wf = win_floats(P.D, P.D2, P.L[l]);
     W.win[l] = wf ? take(wf) : nullptr;
     if (!ws && wf) W.win[l] = reinterpret_cast<float*>(1);   // sizing pass: only the total matters
-    const bool f16 = (wf && pdekan::f16_eligible(P.D, P.D2, P.L[l])) || pdekan::f16_jets12_eligible(P.D, P.D2, P.L[l]);
+    const bool f16 = wf && (pdekan::f16_eligible(P.D, P.D2, P.L[l]) || jets12_f16(P.D, P.D2, P.L[l]));
     W.wpl[l] = f16 ? take(pdekan::f16_wplane_floats(P.L[l])) : nullptr;
   }
   for (size_t l = 0; l <= nl; ++l) {
@@ -584,6 +662,16 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   if (rc) return rc;
   F16Io io;
   const bool f16 = T.wpl && n_dir == 2;
+  if (T.wpl && n_dir == 6 && getenv_flag("PDEKAN_J12_LAYER_DEBUG") && grads && n % 16 == 0) {
+    pdekan::launch_jet_absmax12(x_jet, n * L.I, T.stats + kStatAct, st);
+    pdekan::launch_jet_absmax12(gy_jet, n * L.O, T.stats + kStatCot, st);
+    const int nch = 1;
+    pdekan::launch_bwd_weight12_f16(L, x_jet, gy_jet, part, n, n, L.I / 32, L.O / 64, nch, T.stats + kStatAct,
+                                    T.stats + kStatCot, st);
+    pdekan::launch_reduce_unpack(L, part, nch, part + (size_t)nch * L.packed_floats(), grads->base_weight,
+                                 grads->spline_weight, L.scaler ? grads->spline_scaler : nullptr, accumulate, st);
+    return check_launch("debug");
+  }
   if (f16) {
     pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats + kStatAct, st);
     pdekan::launch_jet_absmax(gy_jet, n * L.O, T.stats + kStatCot, st);
@@ -717,7 +805,16 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       bool cot_ready = head_left_cot;
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
-        if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
+        if (P.D == 6 && W.wpl[l]) {
+          {
+            ProfScope ps(st, "L%d.jet_absmax", l);
+            pdekan::launch_jet_absmax12(W.g[cur], m * P.L[l].O, S.cot(l + 1), st);
+          }
+          F16Io io;
+          io.wpl = W.wpl[l]; io.act_in = S.act(l); io.cot_in = S.cot(l + 1); io.wmax = S.w(l);
+          rc = run_backward_jets12(P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.view, W.part, &grads[l], acc_flag,
+                                   m, st, l, &io);
+        } else if (W.view[0] && split_weight_eligible(P.D, P.D2, P.L[l], m)) {
           bool ga_done = false;
           rc = run_backward_split(P.L[l], W.act[l], W.g[cur], W.win[l], gnext, W.view, W.part, &grads[l], acc_flag, m, st,
                                   l, &ga_done);
