@@ -106,6 +106,11 @@ HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_
                  "bwd_input.mfma_f16x2": "bwd_input_f16_kernel<", "head_fused": "head_bs_kernel<"}
 
 
+# the 12-jet kernels of the same names
+HIP_KERNEL_OF_12 = {"fwd.mfma_f16x2": "fwd12_f16_kernel<", "bwd_input.mfma_f16x2": "bwd_input12_f16_kernel<",
+                    "bwd_weight.mfma_f16x2": "bwd_weight12_f16_kernel<"}
+
+
 def sources_digest():
     """sha256 over the kernel sources: ties a committed counter summary to the code it was measured on."""
     h = hashlib.sha256()
@@ -115,12 +120,13 @@ def sources_digest():
     return h.hexdigest()[:16]
 
 
-def profiled_traffic(kname, name, n_local):
+def profiled_traffic(kname, name, n_local, J=4):
     """HBM bytes per launch of kernel `kname` from a committed rocprofv3 PMC summary under profiles/
     (2 x FETCH_SIZE + WRITE_SIZE, KB; FETCH_SIZE counts half the bytes of wide reads on gfx950).  A summary
     only counts when its header names this workload, this per-GPU point count and the digest of the kernel
     sources it was taken on; otherwise the live line must not quote it."""
-    hip = HIP_KERNEL_OF.get(kname.split(".", 1)[1] if "." in kname else kname)
+    key = kname.split(".", 1)[1] if "." in kname else kname
+    hip = (HIP_KERNEL_OF_12.get(key) if J == 12 else None) or HIP_KERNEL_OF.get(key)
     if hip is None:
         return None, None
     want = f"# workload={name} n_local={n_local} sources={sources_digest()}"
@@ -313,7 +319,8 @@ def main():
     kernels = {}
     for kname, (ms, cnt) in prof.items():
         # 12-jet layers may run the 4-jet matrix / sparse kernels in 5 passes over gathered views: 4 jets per launch
-        Jk = 4 if (J == 12 and (".mfma" in kname or kname.endswith(".sparse"))) else J
+        # (the fp16 two-piece kernels of such a layer take all 12 jets in one launch)
+        Jk = 4 if (J == 12 and ((".mfma" in kname and not kname.endswith(".mfma_f16x2")) or kname.endswith(".sparse"))) else J
         cost = kernel_cost(kname, widths, grid, n_launch_pts, Jk)
         t_roof, bound = roofline_seconds(cost)
         kernels[kname] = {"avg_ms": ms / cnt, "launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
@@ -338,7 +345,7 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kd["avg_ms"],
                 "algorithmic_bytes_per_launch": kd["bytes"]}
-    roof["traffic"], src = profiled_traffic(dom, name, n_local)
+    roof["traffic"], src = profiled_traffic(dom, name, n_local, J)
     if src:
         roof["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)"
     step_dense = sum(k["dense_flops"] * k["launches_per_step"] for k in kernels.values())
