@@ -185,8 +185,10 @@ template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_input_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
                          const float* __restrict__ grid, const float* __restrict__ ginfo, const float* __restrict__ wp,
-                         float* __restrict__ ga, int64_t N, int I, int O, int G, int act, int i0, int IB) {
+                         float* __restrict__ ga, int64_t N, int I, int O, int G, int act, int i0, int IB,
+                         int skip_near_uniform) {
   constexpr int J = 1 + D + D2;
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // a matrix kernel beside this one takes the layer
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
   const int IBe = (I - i0 < IB) ? (I - i0) : IB;          // this launch covers features [i0, i0 + IBe)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,8 +274,9 @@ template <int D, int D2>
 __global__ void __launch_bounds__(256)
 bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__ gy,
                           const float* __restrict__ grid, const float* __restrict__ ginfo, float* __restrict__ part,
-                          int64_t N, int I, int O, int G, int act, int64_t chunk_pts, BwTile T) {
+                          int64_t N, int I, int O, int G, int act, int64_t chunk_pts, BwTile T, int skip_near_uniform) {
   constexpr int J = 1 + D + D2;
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // a matrix kernel beside this one takes the layer
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
   const int TI = T.TI, TO = T.TO, PG = T.PG, PT = T.PT, TE = TI * TO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -603,7 +606,7 @@ static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y,
 
 template <int D, int D2>
 static void bwd_input_t(const LayerView& L, const float* a, const float* gy, const float* wp, float* ga,
-                        int64_t N, hipStream_t st) {
+                        int64_t N, hipStream_t st, bool skip) {
   const int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
   const int64_t total = N * IB;
   int64_t blocks = (total + 255) / 256;
@@ -612,7 +615,7 @@ static void bwd_input_t(const LayerView& L, const float* a, const float* gy, con
   const size_t lds = (size_t)IB * (L.nk() + 1) * 4;
   for (int i0 = 0; i0 < L.I; i0 += IB)
     bwd_input_generic_kernel<D, D2><<<(int)blocks, 256, lds, st>>>(a, gy, L.grid, L.ginfo, wp, ga, N, L.I, L.O, L.G,
-                                                                   L.act, i0, IB);
+                                                                   L.act, i0, IB, skip ? 1 : 0);
 }
 
 static inline int pow2_ceil(int v) { int r = 1; while (r < v) r *= 2; return r; }
@@ -641,7 +644,7 @@ int generic_weight_chunks(int64_t N, int I, int O) {
 
 template <int D, int D2>
 static void bwd_weight_t(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
-                         int64_t N, hipStream_t st) {
+                         int64_t N, hipStream_t st, bool skip) {
   constexpr int J = 1 + D + D2;
   const BwTile T = bw_tile(L.I, L.O);
   int64_t chunk = (N + nchunks - 1) / nchunks;
@@ -650,7 +653,7 @@ static void bwd_weight_t(const LayerView& L, const float* a, const float* gy, fl
   const size_t lds = sizeof(EdgeRec) * T.PT * T.TI + (size_t)T.PT * T.TI * J * 4 + (size_t)T.TI * (L.nk() + 1) * 4 +
                      (size_t)L.C1() * 256 * 4;
   bwd_weight_generic_kernel<D, D2><<<g, 256, lds, st>>>(a, gy, L.grid, L.ginfo, part, N, L.I, L.O, L.G, L.act, chunk,
-                                                        T);
+                                                        T, skip ? 1 : 0);
 }
 
 template <int D, int D2>
@@ -684,16 +687,16 @@ bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const
 }
 
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, const float* wp,
-                              float* ga, int64_t N, hipStream_t st) {
-#define CALL(A, B) bwd_input_t<A, B>(L, a, gy, wp, ga, N, st)
+                              float* ga, int64_t N, hipStream_t st, bool skip_near_uniform) {
+#define CALL(A, B) bwd_input_t<A, B>(L, a, gy, wp, ga, N, st, skip_near_uniform)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
   return true;
 }
 
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
-                               int nchunks, int64_t N, hipStream_t st) {
-#define CALL(A, B) bwd_weight_t<A, B>(L, a, gy, part, nchunks, N, st)
+                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform) {
+#define CALL(A, B) bwd_weight_t<A, B>(L, a, gy, part, nchunks, N, st, skip_near_uniform)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
   return true;

@@ -41,10 +41,10 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t s
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
                         hipStream_t st, bool skip_near_uniform = false);
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
-                              const float* wp, float* ga, int64_t N, hipStream_t st);
+                              const float* wp, float* ga, int64_t N, hipStream_t st, bool skip_near_uniform = false);
 int generic_weight_chunks(int64_t N, int I, int O);
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
-                               int nchunks, int64_t N, hipStream_t st);
+                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform = false);
 // sum_buf: packed_floats() floats of scratch, used when nchunks > 1 or with sel
 // sel.ginfo given: the chunks summed are [first_uniform, + n_uniform) when every knot row of the layer is (nearly)
 // equally spaced, else [first_other, + n_other) - settled on the device (nchunks is not used then)

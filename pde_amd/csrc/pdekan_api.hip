@@ -105,7 +105,7 @@ size_t win_floats(int D, int D2, const pdekan::LayerView& L) {
 
 // layers of a layer-level call that the fp16 matrix kernels take (they need the sparse tables as their fallback)
 bool layer_f16(int D, int D2, const pdekan::LayerView& L) {
-  return (pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0) || pdekan::f16_jets12_eligible(D, D2, L);   // (12 jets: forward only)
+  return (pdekan::f16_eligible(D, D2, L) && win_floats(D, D2, L) > 0) || pdekan::f16_jets12_eligible(D, D2, L);
 }
 // act / cot / w maxima of a layer-level call (256 bytes): a word per jet (4 or 12 used) at kStatAct and kStatCot, one at kStatW
 constexpr size_t kLayerStatWords = 64;
@@ -119,8 +119,19 @@ size_t layer_fwd_floats(int D, int D2, const pdekan::LayerView& L) {
   return f;
 }
 
+size_t jets12_part_chunks(const pdekan::LayerView& L, int64_t n, bool views);
+
+size_t layer_part_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
+  size_t chunks = (size_t)weight_chunks(D, D2, L, n) + 1;
+  if (pdekan::f16_jets12_eligible(D, D2, L)) {
+    const size_t c12 = jets12_part_chunks(L, n, false);
+    if (c12 > chunks) chunks = c12;
+  }
+  return chunks * L.packed_floats();
+}
+
 size_t layer_ws_floats(int D, int D2, const pdekan::LayerView& L, int64_t n) {
-  return layer_fwd_floats(D, D2, L) + align_up((size_t)(weight_chunks(D, D2, L, n) + 1) * L.packed_floats() * 4) / 4;
+  return layer_fwd_floats(D, D2, L) + align_up(layer_part_floats(D, D2, L, n) * 4) / 4;
 }
 
 // What the fp16 matrix kernels of a layer need beside the layer itself: its W planes, the per-jet maxima of its
@@ -290,16 +301,22 @@ bool jets12_f16(int D, int D2, const pdekan::LayerView& L) {
 }
 
 // chunks of partial weight gradients of such a layer on n points: [matrix kernel: nch][last n % 16 points: 1]
-// [split passes: 5 * nch] and one chunk of scratch for the sum
-size_t jets12_part_chunks(const pdekan::LayerView& L, int64_t n) {
+// [what runs instead of the matrix kernel: 5 * nch (split passes, with views) or the streaming kernel's chunks] and
+// one chunk of scratch for the sum
+int jets12_other_chunks(const pdekan::LayerView& L, int64_t n16, int nch, bool views) {
+  if (!n16) return 0;
+  return views ? kSplitPasses * nch : pdekan::generic_weight_chunks(n16, L.I, L.O);
+}
+size_t jets12_part_chunks(const pdekan::LayerView& L, int64_t n, bool views) {
   const int64_t n16 = n / 16 * 16;
   const int nch = n16 ? pdekan::mfma_weight_chunks(n16, L) : 0;
-  return (size_t)nch * (1 + kSplitPasses) + 2;
+  return (size_t)nch + jets12_other_chunks(L, n16, nch, views) + 2;
 }
 
-// Backward of a 12-jet layer for which jets12_f16() holds.  Points [0, n16): the fp16 matrix kernels when every knot
-// row is (nearly) equally spaced, else the split passes - both are launched, the device settles which one works, and
-// the reduction sums the chunks of the one that did.  The last n % 16 points take the streaming kernels.
+// Backward of a 12-jet layer on the fp16 matrix kernels.  Points [0, n16): the matrix kernels when every knot row is
+// (nearly) equally spaced, else the split passes (view given: the fused step) or the streaming kernels (layer-level
+// calls) - both are launched, the device settles which one works, and the reduction sums the chunks of the one that
+// did.  The last n % 16 points take the streaming kernels.
 // h: W planes and the per-slot maxima of a and gy (12 words each).
 int run_backward_jets12(const pdekan::LayerView& L, const float* a, const float* gy, const float* wp, const float* win,
                         float* ga, float* const* view, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
@@ -323,8 +340,12 @@ int run_backward_jets12(const pdekan::LayerView& L, const float* a, const float*
       ProfScope ps(st, "L%d.bwd_input.mfma_f16x2", li);
       pdekan::launch_bwd_input12_f16(L, a, gy, h->wpl, ga, n16, h->cot_in, h->wmax, st);
     }
-    ProfScope ps(st, "L%d.split_passes", li);
-    for (int k = 0; k < kSplitPasses; ++k) {
+    ProfScope ps(st, view ? "L%d.split_passes" : "L%d.bwd.stream", li);
+    if (!view) {
+      if (g) pdekan::launch_bwd_weight_generic(6, 5, L, a, gy, part_split, jets12_other_chunks(L, n16, nch, false), n16, st, true);
+      if (ga) pdekan::launch_bwd_input_generic(6, 5, L, a, gy, wp, ga, n16, st, true);
+    }
+    for (int k = 0; view && k < kSplitPasses; ++k) {
       pdekan::launch_gather_jets4(a, view[0], n16 * L.I, k, true, st, skip);
       pdekan::launch_gather_jets4(gy, view[1], n16 * L.O, k, k == 0, st, skip);
       if (g)
@@ -346,9 +367,9 @@ int run_backward_jets12(const pdekan::LayerView& L, const float* a, const float*
   if (g) {
     ProfScope ps(st, "L%d.reduce_unpack", li);
     const int t = tail ? 1 : 0;
-    pdekan::ChunkSelect sel = {L.ginfo, L.I, 0, nch + t, tail ? nch : nch + 1, t + kSplitPasses * nch};
+    pdekan::ChunkSelect sel = {L.ginfo, L.I, 0, nch + t, tail ? nch : nch + 1, t + jets12_other_chunks(L, n16, nch, view != nullptr)};
     if (!n16) sel = {L.ginfo, L.I, nch, 1, nch, 1};
-    float* sum_buf = part + (jets12_part_chunks(L, n) - 1) * pf;
+    float* sum_buf = part + (jets12_part_chunks(L, n, view != nullptr) - 1) * pf;
     pdekan::launch_reduce_unpack(L, part, 0, sum_buf, g->base_weight, g->spline_weight, L.scaler ? g->spline_scaler : nullptr,
                                  accumulate, st, sel);
   }
@@ -385,7 +406,7 @@ int make_plan(const PdekanLayer* layers, int n_layers, int64_t n, int D, int D2,
       P.view_floats = 1;
     }
     if (jets12_f16(D, D2, P.L[l])) {
-      const size_t ps = jets12_part_chunks(P.L[l], P.mb) * P.L[l].packed_floats();
+      const size_t ps = jets12_part_chunks(P.L[l], P.mb, true) * P.L[l].packed_floats();
       if (ps > pf) pf = ps;
       P.view_floats = 1;
     }
@@ -655,22 +676,18 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   Carver c(ws, ws_bytes);
   LayerTables T;
   const bool tables_ok = carve_layer(c, n_dir, n_second, L, gx_jet != nullptr, T);
-  float* part = c.take((size_t)(weight_chunks(n_dir, n_second, L, n) + 1) * L.packed_floats());
+  float* part = c.take(layer_part_floats(n_dir, n_second, L, n));
   if (!tables_ok || !c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   rc = pack_layer(L, T, st);
   if (rc) return rc;
   F16Io io;
   const bool f16 = T.wpl && n_dir == 2;
-  if (T.wpl && n_dir == 6 && getenv_flag("PDEKAN_J12_LAYER_DEBUG") && grads && n % 16 == 0) {
+  if (T.wpl && n_dir == 6) {
     pdekan::launch_jet_absmax12(x_jet, n * L.I, T.stats + kStatAct, st);
     pdekan::launch_jet_absmax12(gy_jet, n * L.O, T.stats + kStatCot, st);
-    const int nch = 1;
-    pdekan::launch_bwd_weight12_f16(L, x_jet, gy_jet, part, n, n, L.I / 32, L.O / 64, nch, T.stats + kStatAct,
-                                    T.stats + kStatCot, st);
-    pdekan::launch_reduce_unpack(L, part, nch, part + (size_t)nch * L.packed_floats(), grads->base_weight,
-                                 grads->spline_weight, L.scaler ? grads->spline_scaler : nullptr, accumulate, st);
-    return check_launch("debug");
+    io.wpl = T.wpl; io.act_in = T.stats + kStatAct; io.cot_in = T.stats + kStatCot; io.wmax = T.stats + kStatW;
+    return run_backward_jets12(L, x_jet, gy_jet, T.wp, T.win, gx_jet, nullptr, part, grads, accumulate, n, st, 0, &io);
   }
   if (f16) {
     pdekan::launch_jet_absmax(x_jet, n * L.I, T.stats + kStatAct, st);

@@ -125,3 +125,73 @@ def test_per_jet_scales_cover_wide_dynamic_ranges(jet_scale, cot_scale):
             assert max_rel(gx[:, :, j].cpu(), gxref[:, :, j]) <= 1e-5, ("gx", j)
     for name, got, ref in zip(NAMES[2:], (gb, gs, gc), grads[4:]):
         assert max_rel(got.cpu(), ref) <= 1e-5, name
+
+
+# ---- 12 jets (5 assets + time) ----------------------------------------------------------------------------
+def _run12(lay, xj, gy):
+    for p in lay.parameters():
+        p.grad = None
+    x = xj.clone().requires_grad_(True)
+    y = lay.forward_jet(x, 6, 5)
+    y.backward(gy)
+    return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in lay.parameters()]
+
+
+def _jets12(N, I, O_, seed, scale=None):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.ones(12) if scale is None else torch.tensor(scale)
+    xj = torch.randn(N, I, 12, generator=g) * s
+    xj[:, :, 0] = torch.rand(N, I, generator=g) * 3.6 - 1.8          # also outside the extended grid
+    gy = torch.randn(N, O_, 12, generator=g)
+    return xj.cuda(), gy.cuda()
+
+
+@pytest.mark.parametrize("I,O_,N,knots", [(64, 64, 1000, "default"), (128, 128, 2064, "default"), (32, 64, 16, "default"),
+                                          (32, 256, 535, "default"), (256, 64, 48, "default"), (64, 128, 4100, "jittered"),
+                                          (64, 64, 7, "default")])
+def test_fp16_kernels_with_12_jets_agree_with_the_streaming_kernels(I, O_, N, knots, monkeypatch):
+    """Layer-level calls with 6 directions and 5 second derivatives: 8 points x 3 slot groups per wave (forward,
+    input gradients), virtual points (weight gradients), 1 to 4 output blocks, the accumulator flush of wide layers,
+    ragged N (the last N % 8 resp. N % 16 points stream), against the streaming 12-jet kernels."""
+    lay = _layer(I, O_, 10, knots, I + O_ + 1)
+    xj, gy = _jets12(N, I, O_, N)
+    a = _run12(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16", "1")
+    b = _run12(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16")
+    for name, u, v in zip(NAMES, a, b):
+        assert max_rel(u.cpu(), v.cpu()) <= 5e-6, (name, max_rel(u.cpu(), v.cpu()))
+    if N >= 16:
+        assert not torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1]) and not torch.equal(a[3], b[3])
+
+
+def test_12_jet_layers_with_moved_knots_fall_back(monkeypatch):
+    """Knot rows far from equal spacing: the matrix kernels step aside on the device and the streaming kernels
+    launched beside them do the layer.  Outputs and input gradients are theirs bit for bit; the weight gradients are
+    summed over other chunks of points (the last N % 16 points are a chunk of their own), so they agree to rounding."""
+    lay = _layer(64, 64, 10, "moved", 5)
+    xj, gy = _jets12(1000, 64, 64, 6)
+    a = _run12(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16", "1")
+    b = _run12(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for name, u, v in zip(NAMES[2:], a[2:], b[2:]):
+        assert max_rel(u.cpu(), v.cpu()) <= 2e-6, name
+
+
+def test_12_jet_slot_scales_cover_wide_dynamic_ranges(monkeypatch):
+    """Slots that differ by many orders of magnitude: every slot of the outputs and gradients stays within the fp32
+    bar of the streaming kernels' result, measured slot by slot (a shared scale would wipe out the small slots)."""
+    scale = [1.0, 1e3, 1e-3, 1.0, 1e2, 1e-2, 1e-4, 1e6, 1e-6, 1.0, 1e3, 1e-3]
+    lay = _layer(64, 64, 10, "default", 11)
+    xj, gy = _jets12(1024, 64, 64, 12, scale)
+    a = _run12(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16", "1")
+    b = _run12(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16")
+    for j in range(12):
+        assert max_rel(a[0][..., j].cpu(), b[0][..., j].cpu()) <= 5e-6, ("y", j)
+        assert max_rel(a[1][..., j].cpu(), b[1][..., j].cpu()) <= 5e-6, ("gx", j)
+    for name, u, v in zip(NAMES[2:], a[2:], b[2:]):
+        assert max_rel(u.cpu(), v.cpu()) <= 5e-6, name
