@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--micro-batch", type=int, default=0, help="points per micro-batch inside a step (0 = all)")
+    ap.add_argument("--workspace-gb", type=float, default=0.0,
+                    help="bound the library workspace: the largest micro-batch that fits is taken (0 = no bound)")
     ap.add_argument("--base-activation", default="silu", choices=["silu", "identity"],
                     help="silu = the module default (kan.py:18); identity = what the scripts pass (run1.py:478-482)")
     ap.add_argument("--graph", action="store_true",
@@ -260,7 +262,10 @@ def main():
     n_local = hi - lo
 
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    step = BlackScholesStep(model, micro_batch=args.micro_batch)
+    if args.workspace_gb > 0:
+        step = BlackScholesStep(model, workspace_budget=int(args.workspace_gb * 2**30))
+    else:
+        step = BlackScholesStep(model, micro_batch=args.micro_batch)
     dp = DataParallelStep(step, dist, sync="check") if dist is not None else None
     # run1.py:209; one launch for all tensors; capturable keeps the step count on the device (graph replay)
     opt = torch.optim.AdamW(model.parameters(), lr=0.01, fused=True, capturable=args.graph)
@@ -315,6 +320,7 @@ def main():
     torch.cuda.synchronize()
     lib.pdekan_profile_end()
     prof = _lib.profile_results()
+    args.micro_batch = step.micro_batch           # (chosen by the step when a workspace bound is given)
     n_launch_pts = n_local if args.micro_batch <= 0 else min(args.micro_batch, n_local)
     kernels = {}
     for kname, (ms, cnt) in prof.items():

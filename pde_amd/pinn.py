@@ -31,11 +31,19 @@ class BlackScholesStep:
     all-reduce the whole model with a single collective.
     """
 
-    def __init__(self, model: KAN, sigma: float = BS_SIGMA, rate: float = BS_RATE, micro_batch: int = 0):
+    def __init__(self, model: KAN, sigma: float = BS_SIGMA, rate: float = BS_RATE, micro_batch: int = 0,
+                 workspace_budget: Optional[int] = None):
+        """``micro_batch``: points per pass of the library over the batch (0 = all at once); the gradients of the
+        passes are accumulated, the result is that of the whole batch up to summation order.  ``workspace_budget``
+        (bytes): instead of a fixed ``micro_batch``, take the largest one (a multiple of 4096 points, halved until
+        it fits) whose workspace stays within the budget; chosen per batch size at the first call."""
         self.model = model
         self.sigma = float(sigma)
         self.rate = float(rate)
         self.micro_batch = int(micro_batch)
+        self.workspace_budget = None if workspace_budget is None else int(workspace_budget)
+        if self.workspace_budget is not None and self.micro_batch:
+            raise ValueError("give micro_batch or workspace_budget, not both")
         params = list(model.parameters())
         if not params or not params[0].is_cuda:
             raise RuntimeError("pde_amd: move the model to a ROCm GPU before building a BlackScholesStep "
@@ -80,7 +88,24 @@ class BlackScholesStep:
                                        0 if sc is None else by_id[id(sc)].data_ptr())
         return layers, grads, n
 
+    def _fit_micro_batch(self, lib, layers, n_layers, n, d) -> int:
+        """Largest micro-batch (0 = the whole batch) whose workspace fits the budget."""
+        mb = 0
+        while True:
+            need = lib.pdekan_model_workspace_bytes(layers, n_layers, n, d, d - 1, mb)
+            if need == 0:
+                raise _lib.PdekanError(lib.pdekan_last_error().decode())
+            if need <= self.workspace_budget:
+                return mb
+            cur = n if mb == 0 else mb
+            if cur <= 4096:
+                raise _lib.PdekanError(f"pde_amd: a workspace budget of {self.workspace_budget} bytes does not hold "
+                                       f"4096 points of this model ({need} bytes)")
+            mb = max(4096, (cur // 2 + 4095) // 4096 * 4096)
+
     def _workspace(self, lib, layers, n_layers, n, d):
+        if self.workspace_budget is not None and (self._ws_key is None or self._ws_key[:2] != (n, d)):
+            self.micro_batch = self._fit_micro_batch(lib, layers, n_layers, n, d)
         key = (n, d, self.micro_batch)
         if self._ws is None or self._ws_key != key:
             need = lib.pdekan_model_workspace_bytes(layers, n_layers, n, d, d - 1, self.micro_batch)

@@ -225,3 +225,23 @@ def test_jacrev_hessian_callers_stay_on_the_kernels_and_train(golden, monkeypatc
     xs = torch.rand(300, lay.in_features, generator=torch.Generator().manual_seed(1)) * 3.4 - 1.7
     from pde_amd.spline_host import dense_bsplines
     assert max_rel(lay.b_splines(xs.cuda()).cpu(), dense_bsplines(xs, lay.grid.cpu(), 3)) <= 2e-6
+
+
+def test_workspace_budget_picks_a_micro_batch_that_fits():
+    """A byte budget instead of a micro-batch: the step takes the largest micro-batch whose workspace fits, and the
+    gradients equal those of the unbounded step up to summation order."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model([2, 64, 64, 1], 10, 5).cuda()
+    x = torch.rand(20000, 2, generator=torch.Generator().manual_seed(3)).cuda()
+    full = BlackScholesStep(m)
+    loss_full = full(x).item()
+    g_full = full.flat_grad.clone()
+    whole = full._ws.numel()
+    bounded = BlackScholesStep(m, workspace_budget=whole // 3)
+    loss_b = bounded(x).item()
+    assert 0 < bounded.micro_batch < 20000 and bounded.micro_batch % 4096 == 0
+    assert bounded._ws.numel() <= whole // 3
+    assert abs(loss_b - loss_full) <= 1e-6 * abs(loss_full)
+    assert max_rel(bounded.flat_grad.cpu(), g_full.cpu()) <= 3e-6
+    with pytest.raises(Exception, match="budget"):
+        BlackScholesStep(m, workspace_budget=1 << 16)(x)
