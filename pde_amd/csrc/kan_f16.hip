@@ -1926,7 +1926,7 @@ void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* 
 
 template <typename Kern>
 static void allow_lds(Kern k, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
 template <int C1, int ACT, bool GEN>

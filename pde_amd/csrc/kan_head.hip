@@ -51,7 +51,9 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   float* acc = s_acc + wave * I * C1;
   const float hs2 = 0.5f * sigma * sigma;
   float loss_local = 0.0f;
-  float gmax[4] = {0.f, 0.f, 0.f, 0.f};                   // J = 4: per-jet maxima of the cotangents written to ga
+  float gmax[J];                                          // per-jet maxima of the cotangents written to ga
+#pragma unroll
+  for (int j = 0; j < J; ++j) gmax[j] = 0.f;
 
   // A wave works on one point at a time, so the loads of the NEXT point (its jets, coordinates and
   // target) are issued before the current point's arithmetic: their HBM latency hides behind it.
@@ -154,17 +156,15 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
             for (int d = 0; d < D2; ++d) out[1 + D + d] = gy[1 + D + d] * ph1[f];
 #pragma unroll
             for (int j = 0; j < J; ++j) dst[j] = out[j];
-            if constexpr (J == 4) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) gmax[j] = fmaxf(gmax[j], fabsf(out[j]));
-            }
+            for (int j = 0; j < J; ++j) gmax[j] = fmaxf(gmax[j], fabsf(out[j]));
           }
         }
       }
     }
   }
 #undef PDEKAN_HEAD_FETCH
-  if (J == 4 && cot_out && ga) publish_jet_absmax(gmax[0], gmax[1], gmax[2], gmax[3], cot_out);
+  if (cot_out && ga) publish_slot_absmax<J>(gmax, cot_out);
   if (lane == 0) s_loss[wave] = loss_local;
   __syncthreads();
   if (part) {
@@ -219,7 +219,7 @@ static void head_launch(const LayerView& L, const float* a, const float* x, int6
   const size_t lds = head_lds_bytes(L);
   auto k = head_bs_kernel<D, D2, NF>;
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
   k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, L.ginfo, wp, sigma, rate, inv_n, res, ga, part, loss_part,
                                    N, L.I, L.G, L.act, cot_out);
 }

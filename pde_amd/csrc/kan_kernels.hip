@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "kan_math.h"
 #include "kan_launch.h"
+#include "kan_wave.h"
 
 namespace pdekan {
 
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256)
 fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                    const float* __restrict__ wt, float* __restrict__ y,
                    int64_t N, int I, int O, int G, int act, int PT, int NIC, int i0, int IB, int accumulate,
-                   int skip_near_uniform) {
+                   int skip_near_uniform, unsigned* __restrict__ amax_out) {
   constexpr int J = 1 + D + D2;
   if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // a matrix kernel beside this one takes the layer
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
@@ -134,6 +135,9 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
   }
   __syncthreads();
 
+  float amax[J];                              // per-slot maxima of the finished outputs (launch of the last window)
+#pragma unroll
+  for (int j = 0; j < J; ++j) amax[j] = 0.0f;
   const int items = npts * O * NIC;
   const int rounds = (PT * O * NIC + blockDim.x - 1) / blockDim.x;
   for (int rd = 0; rd < rounds; ++rd) {
@@ -170,9 +174,14 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
     if (live && ic == 0) {
       float* dst = y + ((p0 + p) * O + o) * J;
 #pragma unroll
-      for (int j = 0; j < J; ++j) dst[j] = accumulate ? dst[j] + acc[j] : acc[j];
+      for (int j = 0; j < J; ++j) {
+        const float v = accumulate ? dst[j] + acc[j] : acc[j];
+        dst[j] = v;
+        amax[j] = fmaxf(amax[j], fabsf(v));
+      }
     }
   }
+  if (amax_out) publish_slot_absmax<J>(amax, amax_out);
 }
 
 // --------------------------------------------------------------------------
@@ -584,7 +593,8 @@ static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, 
 constexpr int kGenericWindow = 256;
 
 template <int D, int D2>
-static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st, bool skip) {
+static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st, bool skip,
+                  unsigned* amax_out) {
   constexpr int J = 1 + D + D2;
   int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
   const int per_feature = (int)sizeof(EdgeRec) + J * 4 + (L.nk() + 1) * 4;
@@ -601,7 +611,8 @@ static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y,
   const int64_t blocks = (N + PT - 1) / PT;
   for (int i0 = 0; i0 < L.I; i0 += IB)
     fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act,
-                                                                  PT, NIC, i0, IB, i0 > 0, skip ? 1 : 0);
+                                                                  PT, NIC, i0, IB, i0 > 0, skip ? 1 : 0,
+                                                                  (i0 + IB >= L.I) ? amax_out : nullptr);
 }
 
 template <int D, int D2>
@@ -679,8 +690,8 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t sn, int64_t sd, flo
 }
 
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st, bool skip_near_uniform) {
-#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform)
+                        hipStream_t st, bool skip_near_uniform, unsigned* amax_out) {
+#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform, amax_out)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
   return true;

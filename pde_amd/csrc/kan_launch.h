@@ -6,6 +6,10 @@
 
 namespace pdekan {
 
+// Kernels with more than 48 KB of dynamic LDS need the limit raised once per (device, kernel); later launches with
+// no more than what was granted skip the runtime call.  (pdekan_api.hip)
+void ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // One KANLinear layer as the kernels see it (device pointers, caller-owned).
 struct LayerView {
   int I, O, G, act;
@@ -38,8 +42,9 @@ void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, 
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st);
 bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
                       int I, hipStream_t st);
+// amax_out: where the per-slot maxima of y (1 + D + D2 words) are combined into, or nullptr
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st, bool skip_near_uniform = false);
+                        hipStream_t st, bool skip_near_uniform = false, unsigned* amax_out = nullptr);
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
                               const float* wp, float* ga, int64_t N, hipStream_t st, bool skip_near_uniform = false);
 int generic_weight_chunks(int64_t N, int I, int O);
@@ -63,7 +68,7 @@ int head_blocks(int64_t N, const LayerView& L);
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t stride_n, int64_t stride_d,
                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                     float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st,
-                    unsigned* cot_out = nullptr);   // 4-jet models: per-jet maxima of ga are combined into cot_out
+                    unsigned* cot_out = nullptr);   // per-jet maxima of ga (4 or 12 words) are combined into cot_out
 
 // kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
 bool sparse_eligible(int D, int D2, const LayerView& L);

@@ -1046,7 +1046,7 @@ int mfma_weight_chunks(int64_t N, const LayerView& L) {
 
 template <typename Kern>
 static void allow_big_lds(Kern k, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
 template <int C1, int KI>

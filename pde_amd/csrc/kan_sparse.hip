@@ -575,7 +575,7 @@ static size_t sparse_lds(const LayerView& L, bool with_out_stage, int fs = kFS) 
 
 template <typename Kern>
 static void big_lds(Kern k, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
 template <int O, int FS, int RS = 64, bool MG = (RS != 64)>

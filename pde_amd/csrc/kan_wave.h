@@ -60,4 +60,21 @@ __device__ __forceinline__ void publish_jet_absmax(float m0, float m1, float m2,
   }
 }
 
+// the same for any number of slots (12-jet tensors: value, 6 first and 5 second derivatives)
+template <int J>
+__device__ __forceinline__ void publish_slot_absmax(float (&m)[J], unsigned* out) {
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const unsigned mine = __float_as_uint(m[j]);
+      if (mine > __hip_atomic_load(out + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + j, mine);
+    }
+  }
+}
+
 }  // namespace pdekan

@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/pdekan.h"
@@ -13,6 +16,20 @@
 
 // Built-in scratch of pdekan_layer_forward_noalloc (see scratch_of_current_device below).
 static __device__ __align__(256) unsigned char scratch[PDEKAN_NOALLOC_SCRATCH_BYTES];
+
+namespace pdekan {
+void ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[{dev, kernel}];
+  if (g >= bytes) return;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) g = bytes;
+}
+}  // namespace pdekan
 
 namespace {
 
@@ -181,7 +198,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
     pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
   } else {
     ProfScope ps(st, "L%d.fwd.stream", li);
-    if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st))
+    if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st, false, act_out))
       return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
   }
   return check_launch("layer forward");
@@ -524,6 +541,8 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
   // a layer the sparse kernel takes can leave the maxima of its outputs for an fp16 matrix layer above as well
   unsigned* sparse_out = nullptr;
   if (!f16 && l + 1 < nl && W.wpl[l + 1] && W.win[l] && pdekan::sparse_eligible(P.D, P.D2, P.L[l])) sparse_out = S.act(l + 1);
+  // and so can a 12-jet layer on the streaming kernel (the first layer of a 6-input model)
+  if (!f16 && P.D == 6 && l + 1 < nl && W.wpl[l + 1]) sparse_out = S.act(l + 1);
   *act_ready = (f16 && io.act_out != nullptr) || sparse_out != nullptr;
   return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out);
 }
@@ -791,7 +810,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     if (fused_head) {
       const int nblocks = pdekan::head_blocks(m, H);
       // the head's input cotangents feed layer nl-2: leave their per-jet maxima if that layer runs on the fp16 kernels
-      unsigned* head_cot = (grads && nl > 1 && P.D == 2 && W.wpl[nl - 2]) ? S.cot(nl - 1) : nullptr;
+      unsigned* head_cot = (grads && nl > 1 && W.wpl[nl - 2]) ? S.cot(nl - 1) : nullptr;
       head_left_cot = head_cot != nullptr;
       {
         ProfScope ps(st, "L%d.head_fused", nl - 1);
@@ -823,10 +842,11 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       for (int l = top; l >= 0; --l) {
         float* gnext = (l > 0) ? W.g[cur ^ 1] : nullptr;
         if (P.D == 6 && W.wpl[l]) {
-          {
+          if (!cot_ready) {
             ProfScope ps(st, "L%d.jet_absmax", l);
             pdekan::launch_jet_absmax12(W.g[cur], m * P.L[l].O, S.cot(l + 1), st);
           }
+          cot_ready = false;                  // (the 12-jet kernels leave no maxima of what they write)
           F16Io io;
           io.wpl = W.wpl[l]; io.act_in = S.act(l); io.cot_in = S.cot(l + 1); io.wmax = S.w(l);
           rc = run_backward_jets12(P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.view, W.part, &grads[l], acc_flag,
