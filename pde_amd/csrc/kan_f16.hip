@@ -338,6 +338,7 @@ __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsign
 // equally (GEN = true); otherwise it returns at once and fwd_sparse_kernel, launched beside it, does the layer.
 // ==========================================================================================================
 struct WTiles16 { u32x4 h[4], l[4]; };                     // B operands of one k-step: [n]
+struct WTile16 { u32x4 h, l; };                            // B operands of one (k-step, output tile)
 
 __device__ __forceinline__ void load_w16(WTiles16& W, const u32x4* __restrict__ src, int lane, int n) {
   const u32x4* p = src + (n * 2) * 64 + lane;
@@ -357,31 +358,38 @@ struct FwdF16 {
   static constexpr int kStepVecs = 4 * 2 * 64;             // u32x4 per k-step of W planes
   static constexpr int kStageVecs = KS * kStepVecs;
 
-  // One stage.  On entry the E tile holds this stage, cur / nxt its first two A operands, W0 the B operands of its
-  // first k-step and xraw the input jets of the NEXT stage's pairs.  Two waves share a SIMD, so the B operands are
-  // fetched one k-step (4 regions) ahead only, into the buffer the k-step before has just finished with.
+  // One stage = KS k-steps of 4 regions; region (ks, n) multiplies the 4 row tiles of the wave with ONE tile of B
+  // operands (outputs 16n .. 16n+15, both planes): 12 matrix instructions on 4 different accumulators.  A B tile is
+  // needed in one region only, so the tiles come through a ring of 4, each fetched three regions before its use
+  // (with all 4 tiles of a k-step in every region the last of them could be fetched one region ahead at most, and
+  // the waves waited for it).  The A operands of a k-step (4 row tiles) are read during the k-step before, one per
+  // region, into the other half of A.  On entry: the E tile holds this stage, A[FLIP] the row tiles of its first
+  // k-step, the ring the B tiles of its first three regions, xraw the input jets of the NEXT stage's pairs.
   //   region 0            basis of the next stage's pairs (scaled)
   //   region 1            fetch the input jets of the stage after the next; cut columns 0, 1
-  //   region 2            cut columns 2, 3, 4
-  //   region NR-2         park the next stage's planes (every A operand of this stage has been requested)
-  // wsrc: W planes of this stage; wnext: of the next stage (its first k-step is fetched during the last one here).
+  //   region 2, 3         cut columns 2, 3; 4
+  //   region 4 (KS - 1)   every A operand of this stage has been requested: park the next stage's planes; from here
+  //                       on the reads go to the next stage's first k-step
+  // wsrc: W planes of this stage (region i at wsrc + i * 128); wnext: of the next stage.
   template <bool FLIP>
-  static __device__ __forceinline__ void stage(f32x4 (&acc)[4][4], WTiles16& Wa, WTiles16& Wb, ATile16& cur,
-                                               ATile16& nxt, f32x4& xraw, unsigned* sE, const float* knots_next,
-                                               const JetScales& sc, int& prev_c0, const u32x4* __restrict__ wsrc,
-                                               const u32x4* __restrict__ wnext,
+  static __device__ __forceinline__ void stage(f32x4 (&acc)[4][4], WTile16 (&Wr)[4], ATile16 (&A)[2][4], f32x4& xraw,
+                                               unsigned* sE, const float* knots_next, const JetScales& sc, int& prev_c0,
+                                               const u32x4* __restrict__ wsrc, const u32x4* __restrict__ wnext,
                                                const char* __restrict__ xnext2, const int (&aoff)[KS][2], int lane) {
     const int p_local = lane & 15, f_local = lane >> 4;
+    constexpr int kPark = 4 * (KS - 1);
     PairCols pj;
     Planes16 pp[5];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int ks = i >> 2, m = i & 3;
-      const bool odd = ((ks & 1) != 0) != FLIP;            // which buffer holds this k-step
-      WTiles16& Wc = odd ? Wb : Wa;
-      WTiles16& Wn = odd ? Wa : Wb;
-      // one of the 4 output tiles of the next k-step's B operands (both planes)
-      load_w16(Wn, (ks + 1 < KS) ? wsrc + (ks + 1) * kStepVecs : wnext, lane, m);
+      const int ks = i >> 2, n = i & 3;
+      const int cb = ((ks & 1) != 0) != FLIP ? 1 : 0;      // which half of A holds this k-step
+      {                                                    // B tile three regions ahead, into the slot the last region left
+        const int t = i + 3;
+        const u32x4* src = (t < NR) ? wsrc + t * 128 : wnext + (t - NR) * 128;
+        Wr[t & 3].h = src[lane];
+        Wr[t & 3].l = src[64 + lane];
+      }
       if (i == 0) {
         const FeatGrid fg = {knots_next[0], knots_next[nk - 1], fabsf(knots_next[GEN ? nk + 4 : nk])};
         expand_scaled<ACT, GEN>(knots_next, nk, fg, xraw, sc, pj);
@@ -394,20 +402,29 @@ struct FwdF16 {
       if (i == 2) {
         pp[2] = split_jet16(pj.col[2]);
         pp[3] = split_jet16(pj.col[3]);
-        pp[4] = split_jet16(pj.col[4]);
       }
-      if (i == NR - 2) {
+      if (i == 3) pp[4] = split_jet16(pj.col[4]);
+      if (i == kPark) {
         // lgkmcnt counts to 15 only: behind the writes below, a wait for any OLDER read would have to sit out most
         // of the writes too.  The reads in flight were requested a region or more ago: retire them first.
         __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0)
         unsigned* base = sE + (f_local * C1) * kRowWords + p_local * 2;
         park_pair16<C1, PLANE>(base, sE + (f_local * C1) * kRowWords + 32, pp, pj.c0, prev_c0);
       }
-      const int t2 = (i + 2) % NR;             // the last two regions request regions 0 and 1 of the next stage
-      const ATile16 far = read_atile16<PLANE>(sE, aoff[t2 >> 2][0], aoff[t2 >> 2][1], t2 & 3);
-      mfma3x4(acc[m], cur.h, cur.l, Wc.h, Wc.l);
-      cur = nxt;
-      nxt = far;
+      {                                                    // row tile n of the next k-step (of the next stage after the park)
+        const int kn = (ks + 1 < KS) ? ks + 1 : 0;
+        A[cb ^ 1][n] = read_atile16<PLANE>(sE, aoff[kn][0], aoff[kn][1], n);
+      }
+      const f16x8 Bh = __builtin_bit_cast(f16x8, Wr[i & 3].h), Bl = __builtin_bit_cast(f16x8, Wr[i & 3].l);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cb][m].l), Bh, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cb][m].h), Bl, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cb][m].h), Bh, acc[m][n], 0, 0, 0);
       if (i == 0) interleave<12, 8>(); else interleave<12, 4>();
       PDEKAN_REGION_FENCE();
     }
@@ -490,7 +507,8 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (P0 < N) {                              // wave-uniform; no barrier below
-    WTiles16 WA, WB;
+    WTile16 Wr[4];
+    ATile16 A[2][4];
     int prev_c0 = -100;
     f32x4 xraw;
     {
@@ -505,10 +523,10 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
       unsigned* base = sE + (f_local * C1) * kRowWords + p_local * 2;
       park_pair16<C1, F::PLANE>(base, sE + (f_local * C1) * kRowWords + 32, pp, pj.c0, prev_c0);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) load_w16(WA, wbase, lane, n);
+      for (int t = 0; t < 3; ++t) { Wr[t].h = wbase[t * 128 + lane]; Wr[t].l = wbase[t * 128 + 64 + lane]; }
     }
-    ATile16 cur = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 0);
-    ATile16 nxt = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) A[0][m] = read_atile16<F::PLANE>(sE, aoff[0][0], aoff[0][1], m);
     f32x4 tot[LONGK ? 4 : 1][LONGK ? 4 : 1];
     if constexpr (LONGK) {
 #pragma unroll
@@ -519,10 +537,10 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
     for (int s = 0; s < nst; s += 2) {
       // stages past the end: any valid data, expanded and parked but never multiplied
       const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : 0, s3 = (s + 3 < nst) ? s + 3 : 0;
-      F::template stage<false>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s1 * KP, sc, prev_c0,
+      F::template stage<false>(acc, Wr, A, xraw, sE, kbase + 4 * s1 * KP, sc, prev_c0,
                                wbase + (size_t)s * F::kStageVecs, wbase + (size_t)s1 * F::kStageVecs,
                                xrow + (size_t)s2 * 64, aoff, lane);
-      F::template stage<(KS & 1) != 0>(acc, WA, WB, cur, nxt, xraw, sE, kbase + 4 * s2 * KP, sc, prev_c0,
+      F::template stage<(KS & 1) != 0>(acc, Wr, A, xraw, sE, kbase + 4 * s2 * KP, sc, prev_c0,
                                        wbase + (size_t)s1 * F::kStageVecs, wbase + (size_t)s2 * F::kStageVecs,
                                        xrow + (size_t)s3 * 64, aoff, lane);
       if constexpr (LONGK) {
@@ -572,8 +590,6 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
 // Layers wider than 64 outputs are walked 64 outputs at a time; each pass adds its share to the gradients the
 // same lane stored at the same address in the pass before (the chain rule is linear in gE).
 // ==========================================================================================================
-struct WTile16 { u32x4 h, l; };
-
 template <int C1, int ACT, bool GEN>
 struct BwiF16 {
   static constexpr int CP = (C1 + 7) / 8 * 8;
@@ -704,6 +720,7 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
     auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
     fetch_w(Wt[0], wbase);
     fetch_w(Wt[1], wbase + 128);
+    fetch_w(Wt[2], wbase + 256);
 
     f32x4 acc[4][NB];
     // pipeline registers: `cur` = the pair of the stage being multiplied, `prev` = the pair of the stage before with
@@ -728,8 +745,8 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int ks = i / NB, n = i % NB;
-        {                                     // B operand of the region after the next
-          const int t = i + 2;
+        {                                     // B operand three regions ahead (the slot the last region has just left)
+          const int t = i + 3;
           fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
         }
         if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
@@ -746,6 +763,11 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
           const FeatGrid fg = {kn[0], kn[nk - 1], fabsf(kn[GEN ? nk + 4 : nk])};
           eval_pair_d3<ACT, GEN>(kn, nk, fg, cur.x[0], cur.bs, cur.av);
           if (MULTI) old = (ob > 0) ? orow[s * 4] : old;
+        }
+        if (i > NB) {                         // the column tile the region before completed: park it (see below)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * (n - 1) + r) * 4) = acc[m][n - 1];
         }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};   // the first k-step starts the sums (no separate clearing pass)
 #pragma unroll
@@ -764,12 +786,11 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
         if (i == 0) interleave<12, 10>(); else if (i == 1) interleave<12, 8>(); else interleave<12, 2>();
         PDEKAN_REGION_FENCE();
       }
-      // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c
+      // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c.  The tiles
+      // before the last one went out during the regions above (the previous stage's columns were read before them)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-          *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * n + r) * 4) = acc[m][n];
+        *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * (NB - 1) + r) * 4) = acc[m][NB - 1];
       // the 4 + 1 live columns of this lane's pair; a column outside [0, C) reads the base column's slot and is
       // zeroed by a select (no branch)
       const float* drow = sD + p_local * ROW + (f_local * CP) * 4;
