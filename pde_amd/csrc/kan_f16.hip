@@ -615,21 +615,30 @@ __device__ __forceinline__ void eval_pair_d3(const float* knots, int nk, const F
 // what the chain rule of one (point, feature) pair needs once its gE columns are there
 struct PairBack { Basis bs; Act av; f32x4 x; };
 
-// gradient with respect to the input jet of one pair from the gE jets of its 4 + 1 live columns
+// gradient with respect to the input jet of one pair from the gE jets q of its 4 + 1 live columns.  The sums over the
+// columns come first (whole jets at a time: packed FMAs), then the scales are taken out and the jets combined:
+//   d/da_0 = U1_0 + a_1 U2_1 + a_2 U2_2 + a_3 U2_3 + a_1^2 U3_3     d/da_1 = U1_1 + 2 a_1 U2_3
+//   d/da_2 = U1_2                                                     d/da_3 = U1_3
+// with U1, U2, U3 = sum over the columns of q times the first, second, third derivative of the column's basis
+// (of the activation for the base column).
 __device__ __forceinline__ f32x4 chain_rule(const PairBack& pb, const f32x4 (&dcol)[5], const f32x4& inv) {
-  f32x4 out = {0.f, 0.f, 0.f, 0.f};
-  const float s2 = pb.x[1] * pb.x[1];
+  f32x4 U1 = {0.f, 0.f, 0.f, 0.f}, U2 = {0.f, 0.f, 0.f, 0.f};
+  float U3 = 0.f;
 #pragma unroll
   for (int m = 0; m < 5; ++m) {
     const float e1 = m < 4 ? pb.bs.d1[m & 3] : pb.av.f1;
     const float e2 = m < 4 ? pb.bs.d2[m & 3] : pb.av.f2;
     const float e3 = m < 4 ? pb.bs.d3[m & 3] : pb.av.f3;
-    const f32x4 q = dcol[m] * inv;
-    out[0] += q[0] * e1 + (q[1] * pb.x[1] + q[2] * pb.x[2]) * e2 + q[3] * (s2 * e3 + pb.x[3] * e2);
-    out[1] += q[1] * e1 + 2.0f * pb.x[1] * q[3] * e2;
-    out[2] += q[2] * e1;
-    out[3] += q[3] * e1;
+    U1 += dcol[m] * e1;
+    U2 += dcol[m] * e2;
+    U3 += dcol[m][3] * e3;
   }
+  U1 *= inv;
+  U2 *= inv;
+  U3 *= inv[3];
+  f32x4 out = U1;
+  out[0] += pb.x[1] * U2[1] + pb.x[2] * U2[2] + pb.x[3] * U2[3] + pb.x[1] * pb.x[1] * U3;
+  out[1] += 2.0f * pb.x[1] * U2[3];
   return out;
 }
 
@@ -1412,40 +1421,49 @@ struct PairBack12 { Basis bs; Act av; f32x4 x[3]; };
 // inv[j] takes the scales of slot j out of q.
 __device__ __forceinline__ void chain_rule12(const PairBack12& pb, const f32x4 (&dcol)[5][3], const float (&inv)[12],
                                              f32x4 (&out)[3]) {
-  float U1[12], U2[12], U3[5];
+  // sums over the columns, whole groups of four slots at a time (packed FMAs); U3 only for the second-derivative slots
+  f32x4 U1[3], U2[3], U3b = {0.f, 0.f, 0.f, 0.f};
+  float U3a = 0.f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) { U1[j] = 0.f; U2[j] = 0.f; }
-#pragma unroll
-  for (int k = 0; k < 5; ++k) U3[k] = 0.f;
+  for (int g = 0; g < 3; ++g) { U1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; U2[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int m = 0; m < 5; ++m) {
     const float e1 = m < 4 ? pb.bs.d1[m & 3] : pb.av.f1;
     const float e2 = m < 4 ? pb.bs.d2[m & 3] : pb.av.f2;
     const float e3 = m < 4 ? pb.bs.d3[m & 3] : pb.av.f3;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const float q = dcol[m][j >> 2][j & 3];
-      U1[j] += q * e1;
-      if (j >= 1) U2[j] += q * e2;
-      if (j >= 7) U3[j - 7] += q * e3;
+    for (int g = 0; g < 3; ++g) {
+      U1[g] += dcol[m][g] * e1;
+      U2[g] += dcol[m][g] * e2;
     }
+    U3a += dcol[m][1][3] * e3;
+    U3b += dcol[m][2] * e3;
   }
-  float a[12];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) { a[j] = pb.x[j >> 2][j & 3]; U1[j] *= inv[j]; U2[j] *= inv[j]; }
+  for (int g = 0; g < 3; ++g) {
+    const f32x4 iv = {inv[4 * g], inv[4 * g + 1], inv[4 * g + 2], inv[4 * g + 3]};
+    U1[g] *= iv;
+    U2[g] *= iv;
+    if (g == 2) U3b *= iv;
+  }
+  U3a *= inv[7];
+  const float U3[5] = {U3a, U3b[0], U3b[1], U3b[2], U3b[3]};
+  float a[12], u2[12];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) U3[k] *= inv[7 + k];
-  float o[12];
-  o[0] = U1[0];
+  for (int j = 0; j < 12; ++j) { a[j] = pb.x[j >> 2][j & 3]; u2[j] = U2[j >> 2][j & 3]; }
+  float o0 = U1[0][0];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) o[0] += a[1 + k] * U2[1 + k];
+  for (int k = 0; k < 6; ++k) o0 += a[1 + k] * u2[1 + k];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) o[0] += a[7 + k] * U2[7 + k] + a[1 + k] * a[1 + k] * U3[k];
+  for (int k = 0; k < 5; ++k) o0 += a[7 + k] * u2[7 + k] + a[1 + k] * a[1 + k] * U3[k];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { o[1 + k] = U1[1 + k] + 2.0f * a[1 + k] * U2[7 + k]; o[7 + k] = U1[7 + k]; }
-  o[6] = U1[6];
+  for (int g = 0; g < 3; ++g) out[g] = U1[g];
+  out[0][0] = o0;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) out[j >> 2][j & 3] = o[j];
+  for (int k = 0; k < 5; ++k) {
+    const int j = 1 + k;
+    out[j >> 2][j & 3] += 2.0f * a[1 + k] * u2[7 + k];
+  }
 }
 
 // N must be a multiple of 8.  cot_in: per-slot maxima of gy (12 words).
