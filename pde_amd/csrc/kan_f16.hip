@@ -1557,6 +1557,7 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
     auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
     fetch_w(Wt[0], wbase);
     fetch_w(Wt[1], wbase + 128);
+    fetch_w(Wt[2], wbase + 256);
 
     f32x4 acc[6][NB];
     PairBack12 prev, cur;
@@ -1589,7 +1590,7 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
       for (int i = 0; i < NR; ++i) {
         const int ks = i / NB, n = i % NB;
         {
-          const int t = i + 2;
+          const int t = i + 3;                // three regions ahead, into the slot the last region left
           fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
         }
         if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
@@ -1606,6 +1607,11 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
 #pragma unroll
             for (int g = 0; g < 3; ++g) old[g] = orow[s * kStageVec + g];
           }
+        }
+        if (i > NB) {                         // the column tile the region before completed: park it (see below)
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+            *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * (n - 1) + r) * 12 + 4 * (m >> 1)) = acc[m][n - 1];
         }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1625,11 +1631,10 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
         PDEKAN_REGION_FENCE();
       }
       // park the stage's gE tile: lane (c = r, q = kb) holds slots 4g .. 4g+3 of point 4pq + q, column 16n + c
+      // (the tiles before the last one went out during the regions above)
 #pragma unroll
       for (int m = 0; m < 6; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-          *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * n + r) * 12 + 4 * (m >> 1)) = acc[m][n];
+        *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * (NB - 1) + r) * 12 + 4 * (m >> 1)) = acc[m][NB - 1];
       const float* drow = sD + p_local * ROW + (f_local * CP) * 12;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
