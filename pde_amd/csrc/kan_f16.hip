@@ -1178,6 +1178,19 @@ __device__ __forceinline__ void expand12(const float* knots, int nk, const FeatG
   out.c0 = bs.c0;
 }
 
+struct PairKeep12x { Basis bs; Act av; };                   // basis and activation of a pair, kept over several regions
+
+// one expanded column (m = 0..3 live spline columns, 4 = base column) of all three groups, from the pieces above
+__device__ __forceinline__ void column12(const PairKeep12x& pk, const RowCoefs12& rc, int m, f32x4 (&col)[3]) {
+  const float b0 = m < 4 ? pk.bs.b[m & 3] : pk.av.f0, b1 = m < 4 ? pk.bs.d1[m & 3] : pk.av.f1;
+  const float b2 = m < 4 ? pk.bs.d2[m & 3] : pk.av.f2;
+  col[0] = rc.be[0] * b1;
+  col[0][0] = rc.s0 * b0;
+  col[1] = rc.be[1] * b1;
+  col[1][3] += rc.ga[1][3] * b2;
+  col[2] = rc.be[2] * b1 + rc.ga[2] * b2;
+}
+
 __device__ __forceinline__ Planes12 split_col12(const f32x4 (&c)[3]) {
   Planes12 p;
 #pragma unroll
@@ -1233,9 +1246,13 @@ struct Fwd12 {
   static constexpr int kStepVecs = 4 * 2 * 64;
   static constexpr int kStageVecs = KS * kStepVecs;
 
-  //   region 0            basis and rows of the next stage's pairs (scaled)
-  //   region 1            fetch the input jets of the stage after the next
-  //   regions 1 .. 5      cut one column each
+  // The expansion of the next stage's pairs is spread over the regions, a few vector instructions behind each matrix
+  // instruction (one wave per SIMD: whatever vector work sits between two matrix instructions is time the matrix
+  // pipe idles once it exceeds two instructions):
+  //   region 0            basis and activation of the pairs
+  //   region 1            row coefficients of the three groups; fetch the input jets of the stage after the next
+  //   regions 1 .. 5      column m = region - 1 of all groups
+  //   regions 2 .. 6      cut column m = region - 2
   //   region NR-2         park the next stage's planes
   template <bool FLIP>
   static __device__ __forceinline__ void stage(f32x4 (&acc)[6][4], WTiles16& Wa, WTiles16& Wb, ATile16& cur, ATile16& nxt,
@@ -1243,8 +1260,11 @@ struct Fwd12 {
                                                const SlotScales12& sc, int& prev_c0, const u32x4* __restrict__ wsrc,
                                                const u32x4* __restrict__ wnext, const char* __restrict__ xnext2,
                                                const int (&aoff)[KS][2], int lane) {
+    static_assert(NR >= 9, "the plan below needs 7 regions before the park");
     const int p_local = lane & 7, f_local = (lane >> 3) & 3;
-    PairCols12 pj;
+    PairKeep12x pk;
+    RowCoefs12 rc;
+    f32x4 col[3];
     Planes12 pp[5];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -1253,26 +1273,30 @@ struct Fwd12 {
       WTiles16& Wc = odd ? Wb : Wa;
       WTiles16& Wn = odd ? Wa : Wb;
       if (m < 4) load_w16(Wn, (ks + 1 < KS) ? wsrc + (ks + 1) * kStepVecs : wnext, lane, m);
+      if (i >= 2 && i <= 6) pp[i - 2] = split_col12(col);           // (the column the region before computed)
       if (i == 0) {
         const FeatGrid fg = {knots_next[0], knots_next[nk - 1], fabsf(knots_next[GEN ? nk + 4 : nk])};
-        expand12<ACT, GEN>(knots_next, nk, fg, xraw, sc, pj);
+        if constexpr (GEN) eval_basis_near_uniform(knots_next, nk, fg.g0, fg.glast, fg.inv_h, xraw[0][0], pk.bs);
+        else eval_basis_uniform_by_quotient(knots_next, nk, fg.g0, fg.glast, fg.inv_h, xraw[0][0], pk.bs);
+        pk.av = eval_act(ACT, xraw[0][0]);
       }
       if (i == 1) {
+        rc = row_coefs12(xraw, sc);
 #pragma unroll
         for (int g = 0; g < 3; ++g) xraw[g] = *reinterpret_cast<const f32x4*>(xnext2 + 16 * g);
       }
-      if (i >= 1 && i <= 5) pp[i - 1] = split_col12(pj.col[i - 1]);
+      if (i >= 1 && i <= 5) column12(pk, rc, i - 1, col);
       if (i == NR - 2) {
         __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): retire the reads in flight before the run of writes
         unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
-        park_pair12<C1, PLANE>(base, sE + (ROWS - 1) * kRowWords12 + p_local * 2, pp, pj.c0, prev_c0);
+        park_pair12<C1, PLANE>(base, sE + (ROWS - 1) * kRowWords12 + p_local * 2, pp, pk.bs.c0, prev_c0);
       }
       const int t2 = (i + 2) % NR;
       const ATile16 far = read_atile16<PLANE>(sE, aoff[t2 / 6][0], aoff[t2 / 6][1], t2 % 6);
       mfma3x4(acc[m], cur.h, cur.l, Wc.h, Wc.l);
       cur = nxt;
       nxt = far;
-      if (i == 0) interleave<12, 12>(); else interleave<12, 4>();
+      if (i <= 6) interleave<12, 5>(); else interleave<12, 3>();
       PDEKAN_REGION_FENCE();
     }
   }
