@@ -135,14 +135,21 @@ def profiled_traffic(kname, name, n_local, J=4):
             lines = f.read().splitlines()
         if not lines or lines[0].strip() != want:
             continue
+        # several instantiations of a kernel template may be launched side by side (the ones that do not match the
+        # layer's knot rows return at once): the one that did the work is the one with the longest launches
         fetch = write = None
+        best = {"FETCH_SIZE=": -1.0, "WRITE_SIZE=": -1.0}
         for line in lines:
-            if line.startswith(hip.split("<")[0]) and hip in line:
+            if line.startswith(hip.split("<")[0]) and hip in line and "avg_ms=" in line:
+                avg = float(line.split("avg_ms=")[1].split()[0])
                 for tok in line.split():
-                    if tok.startswith("FETCH_SIZE="):
-                        fetch = float(tok.split("=")[1])
-                    if tok.startswith("WRITE_SIZE="):
-                        write = float(tok.split("=")[1])
+                    for key in best:
+                        if tok.startswith(key) and avg > best[key]:
+                            best[key] = avg
+                            if key == "FETCH_SIZE=":
+                                fetch = float(tok.split("=")[1])
+                            else:
+                                write = float(tok.split("=")[1])
         if fetch is not None and write is not None:
             return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
     return None, None
