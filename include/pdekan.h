@@ -78,8 +78,9 @@ int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t
                      int32_t n_dir, int32_t n_second, float* jet, void* stream);
 
 /* KANLinear.b_splines (kan.py:78-111), dense, and its derivatives with respect to x as autograd would form them:
- * out[N][in][grid_size + spline_order] = d^order B_c(x[n][i]) / dx^order for x[N][in] (contiguous), order 0..3
- * (half-open knot intervals, zero outside the extended grid; the fourth derivative of a cubic is zero).  This is
+ * out[N][in][grid_size + spline_order] = d^order B_c(x[n][i]) / dx^order for x[N][in] (contiguous), on the layer's
+ * grid[in][grid_size + 2 * spline_order + 1]; spline_order 0..5, order 0..6 (half-open knot intervals, zero outside
+ * the extended grid; derivatives beyond the spline order are zero).  This is
  * the one piece of KANLinear.forward that torch.func transforms (jacrev / hessian, run1.py:122-124) cannot trace
  * through a library call: with it as an elementwise op that knows its own derivative, forward under those
  * transforms is two GEMMs around this kernel. */

@@ -561,10 +561,67 @@ __global__ void basis_dense_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
-void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st) {
+// The same for any spline order k <= kMaxAnyOrder (the layers whose order is not 3 run `forward` as its defining
+// expression around this kernel): dense bases B_{c,k}, c < G + k, or their r-th derivative, on nk = G + 2k + 1 knots.
+// One thread per (point, feature): the interval s with t_s <= x < t_{s+1} (half-open as kan.py:94; x outside the
+// knots: all zero), then the k + 1 bases alive on it by the Cox-de Boor recursion restricted to them (kan.py:96-108)
+// up to order k - r, then r steps of  D B_{i,d} = d (B_{i,d-1} / (t_{i+d} - t_i) - B_{i+1,d-1} / (t_{i+d+1} - t_{i+1})).
+// w[m] stands for basis i = s - k + m; terms whose knots would fall outside the row belong to bases that do not exist.
+constexpr int kMaxAnyOrder = 5;
+
+__global__ void basis_dense_any_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
+                                       int64_t total, int I, int nk, int k, int r) {
+  const int C = nk - k - 1;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const float* g = grid + (size_t)(t % I) * nk;
+    const float xv = x[t];
+    float* dst = out + t * C;
+    int s = -1;
+    for (int q = 0; q + 1 < nk; ++q)
+      if (xv >= g[q] && xv < g[q + 1]) s = q;
+    float w[kMaxAnyOrder + 2];
+#pragma unroll
+    for (int m = 0; m < kMaxAnyOrder + 2; ++m) w[m] = 0.0f;
+    if (s >= 0 && r <= k) {
+      w[k] = 1.0f;                                         // order 0: the indicator of interval s is basis i = s
+      for (int d = 1; d <= k; ++d) {
+        const bool deriv = d > k - r;
+#pragma unroll
+        for (int m = 0; m <= kMaxAnyOrder; ++m) {
+          if (m > k) continue;
+          const int i = s - k + m;
+          float left = 0.0f, right = 0.0f;
+          if (i >= 0 && i + d < nk) {
+            const float den = g[i + d] - g[i];
+            left = deriv ? w[m] / den : (xv - g[i]) / den * w[m];
+          }
+          if (i + 1 >= 0 && i + d + 1 < nk) {
+            const float den = g[i + d + 1] - g[i + 1];
+            right = deriv ? -w[m + 1] / den : (g[i + d + 1] - xv) / den * w[m + 1];
+          }
+          w[m] = deriv ? (float)d * (left + right) : left + right;
+        }
+      }
+    }
+    for (int c = 0; c < C; ++c) {
+      const int m = c - (s - k);
+      float v = 0.0f;
+#pragma unroll
+      for (int q = 0; q <= kMaxAnyOrder; ++q) v = (q == m) ? w[q] : v;
+      dst[c] = (s >= 0 && m >= 0 && m <= k) ? v : 0.0f;
+    }
+  }
+}
+
+void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st,
+                        int spline_order) {
   const int64_t total = N * I;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (spline_order != kOrder) {
+    basis_dense_any_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, grid, out, total, I, G + 2 * spline_order + 1, spline_order, order);
+    return;
+  }
   basis_dense_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, grid, out, total, I, G + 2 * kOrder + 1, G + kOrder, order);
 }
 

@@ -33,7 +33,9 @@ struct ChunkSelect { const float* ginfo = nullptr; int I = 0, first_uniform = 0,
 // kan_kernels.hip
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st);
 // out[N][I][G+3] = order-th derivative of every cubic basis at x[N][I]
-void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st);
+// (spline_order 0 .. 5; 3 takes the local cubic evaluation)
+void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N, int I, int G, int order, hipStream_t st,
+                        int spline_order = 3);
 // out4[e] = (value or 0, first k, first 5 in pass 0 else 0, second k) of in12[e], e < elems, k = 0..4
 void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, bool keep_value, hipStream_t st,
                          JetSkip skip = {});

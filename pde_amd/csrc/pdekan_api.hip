@@ -646,10 +646,15 @@ int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t
 int pdekan_basis_dense(const float* grid, const float* x, int64_t n, int32_t in_features, int32_t grid_size,
                        int32_t spline_order, int32_t order, float* out, void* stream) {
   if (!grid || !x || !out || n < 1 || in_features < 1) return fail(PDEKAN_ERR_ARG, "basis_dense: bad arguments");
-  if (spline_order != 3) return fail(PDEKAN_ERR_ARG, "spline_order %d unsupported (cubic only)", spline_order);
+  if (spline_order < 0 || spline_order > 5) return fail(PDEKAN_ERR_ARG, "basis_dense: spline_order %d unsupported (0..5)", spline_order);
   if (grid_size < 1 || grid_size > 64) return fail(PDEKAN_ERR_ARG, "bad grid_size %d", grid_size);
-  if (order < 0 || order > 3) return fail(PDEKAN_ERR_ARG, "derivative order %d: 0..3 (the fourth derivative of a cubic is zero)", order);
-  pdekan::launch_basis_dense(x, grid, out, n, in_features, grid_size, order, (hipStream_t)stream);
+  if (order < 0 || order > 6) return fail(PDEKAN_ERR_ARG, "derivative order %d: 0..6 (orders above the spline order give zeros)", order);
+  if (spline_order == 3 && order > 3) {
+    if (hipMemsetAsync(out, 0, (size_t)n * in_features * (grid_size + 3) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return fail(PDEKAN_ERR_HIP, "basis_dense: clearing the output failed");
+    return PDEKAN_OK;
+  }
+  pdekan::launch_basis_dense(x, grid, out, n, in_features, grid_size, order, (hipStream_t)stream, spline_order);
   return check_launch("basis_dense");
 }
 

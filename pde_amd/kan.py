@@ -86,7 +86,7 @@ class KANLinear(torch.nn.Module):
     def b_splines(self, x: torch.Tensor):
         """Dense bases ``(batch, in_features, grid_size + spline_order)`` (kan.py:78-111)."""
         assert x.dim() == 2 and x.size(1) == self.in_features
-        if x.is_cuda and self.spline_order == 3 and x.dtype == torch.float32:
+        if x.is_cuda and 0 <= self.spline_order <= 5 and x.dtype == torch.float32:
             return K.basis_dense(x, self.grid, self.grid_size, self.spline_order)     # the library's basis kernel
         return dense_bsplines(x, self.grid, self.spline_order)
 
@@ -117,7 +117,8 @@ class KANLinear(torch.nn.Module):
         flat = x.reshape(-1, self.in_features)
         kind = _act_kind(self.base_activation)
         grid, bw, sw, sc = self._kernel_params()
-        if _under_func_transform(flat):
+        if _under_func_transform(flat) or self.spline_order != 3:
+            # Spline orders other than 3 (no reference caller uses one; the whole-layer kernels are cubic) and
             # torch.func transforms (the scripts' jacrev / hessian, run1.py:122-124) trace through tensor ops and
             # cannot see inside a whole-layer library call.  Under them the layer is its defining expression
             # (kan.py:153-166): two GEMMs around the dense bases.  On a GPU the bases come from the library's
@@ -125,7 +126,7 @@ class KANLinear(torch.nn.Module):
             # (functional.basis_dense), so jacrev / hessian of any depth stay on it; on a CPU tensor (no kernels
             # there) they are plain tensor code.  O(n^2)/O(n^3) like the scripts either way; forward_jet gives the
             # same derivatives in O(n).
-            if grid.is_cuda and self.spline_order == 3:
+            if grid.is_cuda and 0 <= self.spline_order <= 5:
                 bases = K.basis_dense(flat, grid, self.grid_size, self.spline_order)
             else:
                 bases = dense_bsplines(flat, grid, self.spline_order)

@@ -245,3 +245,53 @@ def test_workspace_budget_picks_a_micro_batch_that_fits():
     assert max_rel(bounded.flat_grad.cpu(), g_full.cpu()) <= 3e-6
     with pytest.raises(Exception, match="budget"):
         BlackScholesStep(m, workspace_budget=1 << 16)(x)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 5])
+def test_spline_orders_other_than_cubic(k):
+    """`spline_order` is a constructor argument of the mirrored module (kan.py:12).  The whole-layer kernels are cubic;
+    other orders run `forward` as its defining expression (kan.py:153-166) around the library's any-order basis kernel,
+    which carries its own derivative: bases and their first two derivatives against autograd through the fp64
+    oracle's Cox-de Boor recursion (kan.py:78-111), then a layer's forward and parameter / input gradients."""
+    from pde_amd import functional as K
+    from pde_amd.kan import KANLinear
+    torch.manual_seed(k)
+    I, O_, G, N = 7, 5, 6, 400
+    lay = KANLinear(I, O_, grid_size=G, spline_order=k).cuda()
+    with torch.no_grad():
+        lay.grid[:, 3] += 0.03                                            # not equally spaced
+        for p in lay.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    x = (torch.rand(N, I, generator=torch.Generator().manual_seed(2)) * 2.6 - 1.3).cuda()   # also off the base grid
+    x64 = x.double().cpu().requires_grad_(True)
+    g64 = lay.grid.double().cpu()
+    b64 = O.b_splines(x64, g64, k)
+    assert b64.shape == (N, I, G + k)
+    got = K.basis_dense(x, lay.grid, G, k)
+    assert max_rel(got.cpu(), b64.detach()) <= 2e-6
+    cur = b64
+    for order in (1, 2):
+        # derivative of every basis with respect to its own input: one backward pass per basis index
+        if order > k:                                                     # beyond the order: piecewise zero
+            cur = torch.zeros_like(b64)
+        else:
+            cols = [torch.autograd.grad(cur[:, :, c].sum(), x64, create_graph=True)[0] for c in range(G + k)]
+            cur = torch.stack(cols, dim=-1)
+        got = K.basis_dense(x, lay.grid, G, k, order)
+        scale = cur.detach().abs().max().clamp_min(1e-30)
+        assert ((got.cpu().double() - cur.detach()).abs().max() / scale).item() <= 5e-6, order
+    # the layer
+    xg = x.clone().requires_grad_(True)
+    y = lay(xg)
+    w = torch.randn(N, O_, generator=torch.Generator().manual_seed(3)).cuda()
+    (y * w).sum().backward()
+    p64 = {n_: (p.detach().double().cpu().requires_grad_(True)) for n_, p in lay.named_parameters()}
+    q = {"grid": g64, "base_weight": p64["base_weight"], "spline_weight": p64["spline_weight"],
+         "spline_scaler": p64["spline_scaler"]}
+    xr = x.double().cpu().requires_grad_(True)
+    yr = O.layer_forward(xr, q, "silu", spline_order=k)
+    (yr * w.double().cpu()).sum().backward()
+    assert max_rel(y.detach().cpu(), yr.detach()) <= TOL
+    assert max_rel(xg.grad.cpu(), xr.grad) <= TOL
+    for n_, p in lay.named_parameters():
+        assert max_rel(p.grad.cpu(), p64[n_].grad) <= TOL, n_
