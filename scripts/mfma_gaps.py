@@ -19,7 +19,9 @@ for n, l in enumerate(body):
         t = m.group(1) or m.group(2)
         if t in lab and lab[t] < n: loops.append((n - lab[t], lab[t], n))
 loops.sort(reverse=True)
-L, a, b = loops[0]
+# the innermost loop that still holds matrix instructions: the smallest one with at least 48 of them
+cands = [(L, a, b) for (L, a, b) in loops if sum(1 for l in body[a:b] if l.strip().startswith('v_mfma')) >= 48]
+L, a, b = min(cands) if cands else loops[0]
 gaps, cur, kinds = [], 0, Counter()
 tot = Counter()
 for l in body[a:b]:
