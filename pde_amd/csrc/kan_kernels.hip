@@ -173,11 +173,28 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
     }
     if (live && ic == 0) {
       float* dst = y + ((p0 + p) * O + o) * J;
+      if constexpr (J % 4 == 0) {               // whole jets as 16-byte accesses (a jet of 4 or 12 floats is 16-byte aligned)
+        float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const float v = accumulate ? dst[j] + acc[j] : acc[j];
-        dst[j] = v;
-        amax[j] = fmaxf(amax[j], fabsf(v));
+        for (int q = 0; q < J / 4; ++q) {
+          float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          if (accumulate) {
+            const float4 old = d4[q];
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+          }
+          d4[q] = v;
+          amax[4 * q] = fmaxf(amax[4 * q], fabsf(v.x));
+          amax[4 * q + 1] = fmaxf(amax[4 * q + 1], fabsf(v.y));
+          amax[4 * q + 2] = fmaxf(amax[4 * q + 2], fabsf(v.z));
+          amax[4 * q + 3] = fmaxf(amax[4 * q + 3], fabsf(v.w));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float v = accumulate ? dst[j] + acc[j] : acc[j];
+          dst[j] = v;
+          amax[j] = fmaxf(amax[j], fabsf(v));
+        }
       }
     }
   }
@@ -332,8 +349,16 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
         const EdgeRec r = recs[pp * TI + ti];
         float g[J];
         const float* gsrc = gy + ((pb + pp) * O + o) * J;
+        if constexpr (J % 4 == 0) {             // whole jets as 16-byte loads
 #pragma unroll
-        for (int j = 0; j < J; ++j) g[j] = gsrc[j];
+          for (int q = 0; q < J / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(gsrc)[q];
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < J; ++j) g[j] = gsrc[j];
+        }
         float A0, A1, A2;
         jet_pullback_coeffs<D, D2>(g, s_jet + (pp * TI + ti) * J, A0, A1, A2);
         s_acc[C * 256 + threadIdx.x] += A0 * r.f0 + A1 * r.f1 + A2 * r.f2;
