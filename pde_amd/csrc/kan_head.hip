@@ -20,6 +20,12 @@
 
 namespace pdekan {
 
+// LDS rows of the packed weights and of the gradient tables are PADDED: 3 columns in front of and behind the C
+// spline columns (so the 4 live columns c0..c0+3, c0 in [-3, C-1] + what a row of knots allows, are always inside
+// the row and need no masking: the pads hold zero weights and collect sums nobody reads), then the base column.
+// Row I (all zero) serves the lanes past the last feature.
+__device__ __forceinline__ int head_row_words(int C) { return C + 7; }
+
 template <int D, int D2, int NF>
 __global__ void __launch_bounds__(256)
 head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
@@ -30,30 +36,61 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
                unsigned* __restrict__ cot_out) {
   constexpr int J = 1 + D + D2;
   static_assert(D2 == D - 1, "assets first, time last");
-  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  static_assert(J % 4 == 0, "output jets are summed over the wave four at a time");
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1, CP = head_row_words(C);
   const int nw = blockDim.x >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int kr = nk + 1;                                  // knots + the feature's 1/h (0 = not equally spaced)
+  const int tab = (I + 1) * CP;
   float* s_knots = reinterpret_cast<float*>(smem);        // [I][kr]
-  float* s_w = s_knots + I * kr;                          // [I][C1]
-  float* s_acc = s_w + I * C1;                            // [nw][I][C1]
-  float* s_loss = s_acc + nw * I * C1;                    // [nw]
+  float* s_w = s_knots + I * kr;                          // [I+1][CP]
+  float* s_acc = s_w + tab;                               // [nw][I+1][CP]
+  float* s_loss = s_acc + nw * tab;                       // [nw]
 
   for (int t = threadIdx.x; t < I * kr; t += blockDim.x) {
     const int f = t / kr, k = t - f * kr;
     s_knots[t] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
   }
-  for (int t = threadIdx.x; t < I * C1; t += blockDim.x) s_w[t] = wp[t];
-  for (int t = threadIdx.x; t < nw * I * C1; t += blockDim.x) s_acc[t] = 0.0f;
+  for (int t = threadIdx.x; t < tab; t += blockDim.x) {
+    const int i = t / CP, k = t - i * CP;
+    float v = 0.0f;
+    if (i < I) {
+      if (k >= 3 && k < C + 3) v = wp[i * C1 + k - 3];
+      else if (k == C + 6) v = wp[i * C1 + C];
+    }
+    s_w[t] = v;
+  }
+  for (int t = threadIdx.x; t < nw * tab; t += blockDim.x) s_acc[t] = 0.0f;
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* acc = s_acc + wave * I * C1;
+  // the wave index, and with it the point a wave works on, is kept in scalar registers: row addresses are then
+  // scalar arithmetic and the per-lane part of every address is a constant offset
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float hs2 = 0.5f * sigma * sigma;
   float loss_local = 0.0f;
   float gmax[J];                                          // per-jet maxima of the cotangents written to ga
 #pragma unroll
   for (int j = 0; j < J; ++j) gmax[j] = 0.f;
+
+  // what a lane keeps about its NF features for the whole kernel
+  const float* krow[NF];
+  const float* wrow[NF];
+  float* arow[NF];
+  float g0[NF], glast[NF], invh[NF], wbase[NF];
+  int joff[NF];
+  bool live[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int i = lane + 64 * f;
+    live[f] = i < I;
+    const int ic = live[f] ? i : 0, iw = live[f] ? i : I;
+    krow[f] = s_knots + ic * kr;
+    g0[f] = krow[f][0]; glast[f] = krow[f][nk - 1]; invh[f] = krow[f][nk];
+    wrow[f] = s_w + iw * CP + 3;
+    arow[f] = s_acc + wave * tab + iw * CP + 3;
+    wbase[f] = wrow[f][C + 3];
+    joff[f] = ic * J;
+  }
 
   // A wave works on one point at a time, so the loads of the NEXT point (its jets, coordinates and
   // target) are issued before the current point's arithmetic: their HBM latency hides behind it.
@@ -63,10 +100,9 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
 #define PDEKAN_HEAD_FETCH(PP)                                                          \
   {                                                                                    \
     const int64_t pp_ = ((PP) < N) ? (PP) : N - 1;                                     \
+    const float* src_ = a + pp_ * I * J;                                               \
     _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                   \
-      const int i_ = lane + 64 * f;                                                    \
-      const float* src_ = a + (pp_ * I + (i_ < I ? i_ : 0)) * J;                       \
-      _Pragma("unroll") for (int j = 0; j < J; ++j) jetn[f][j] = src_[j];              \
+      _Pragma("unroll") for (int j = 0; j < J; ++j) jetn[f][j] = src_[joff[f] + j];    \
     }                                                                                  \
     _Pragma("unroll") for (int d = 0; d < D2; ++d) xsn[d] = x[pp_ * stride_n + d * stride_d]; \
     tgtn = target ? target[pp_] : 0.0f;                                                \
@@ -92,34 +128,29 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
     for (int j = 0; j < J; ++j) y[j] = 0.0f;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const int i = lane + 64 * f;
-      const bool live = i < I;
-      const int ic = live ? i : 0;
-      eval_basis_row<true>(s_knots + ic * kr, nk, jet[f][0], bs[f]);
+      if (invh[f] > 0.0f) eval_basis_uniform_oneshot<true>(krow[f], nk, g0[f], glast[f], invh[f], jet[f][0], bs[f]);
+      else eval_basis<true>(krow[f], nk, jet[f][0], bs[f]);
       av[f] = eval_act(act, jet[f][0]);
-      const float* w = s_w + ic * C1;
-      const float wb = live ? w[C] : 0.0f;
+      const float* w = wrow[f] + bs[f].c0;
+      const float wb = wbase[f];
       float p0 = wb * av[f].f0, p1 = wb * av[f].f1, p2 = wb * av[f].f2, p3 = wb * av[f].f3;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int c = bs[f].c0 + m;
-        const float wm = (live && c >= 0 && c < C) ? w[c] : 0.0f;
+        const float wm = w[m];
         p0 += wm * bs[f].b[m]; p1 += wm * bs[f].d1[m]; p2 += wm * bs[f].d2[m]; p3 += wm * bs[f].d3[m];
       }
       ph1[f] = p1; ph2[f] = p2; ph3[f] = p3;
       jet_accumulate<D, D2>(y, jet[f], p0, p1, p2);
     }
-    // wavefront sum on the VALU (DPP + permlane swaps): every lane ends up with the full sums
+    // wavefront sums on the VALU (DPP + permlane swaps), four jets at a time; the results are wave-uniform
 #pragma unroll
-    for (int j = 0; j < J; ++j) y[j] = wave_sum(y[j]);
+    for (int j = 0; j < J; j += 4) wave_sum4(y[j], y[j + 1], y[j + 2], y[j + 3]);
     float res = y[D] + rate * y[0];
 #pragma unroll
     for (int d = 0; d < D2; ++d) res = res - hs2 * xs[d] * xs[d] * y[1 + D + d] - rate * xs[d] * y[1 + d];
     const float diff = res - tgt;
-    if (lane == 0) {
-      loss_local += diff * diff;
-      if (res_out) res_out[p] = res;
-    }
+    loss_local += diff * diff;                            // the same in every lane
+    if (lane == 0 && res_out) res_out[p] = res;
     if (part || ga) {
       const float g = 2.0f * diff * inv_n;
       float gy[J];
@@ -127,38 +158,34 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
 #pragma unroll
       for (int d = 0; d < D2; ++d) { gy[1 + d] = -g * rate * xs[d]; gy[1 + D + d] = -g * hs2 * xs[d] * xs[d]; }
       gy[D] = g;
+      float* dst_row = ga + p * I * J;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const int i = lane + 64 * f;
-        if (i < I) {
-          float A0, A1, A2;
-          jet_pullback_coeffs<D, D2>(gy, jet[f], A0, A1, A2);
-          if (part) {
-            float* row = acc + i * C1;
-            row[C] += A0 * av[f].f0 + A1 * av[f].f1 + A2 * av[f].f2;
+        float A0, A1, A2;
+        jet_pullback_coeffs<D, D2>(gy, jet[f], A0, A1, A2);
+        // (lanes past the last feature add into the spare row; plain read-add-write: the LDS unit's own float add,
+        // ds_add_f32, measured 4x slower for the whole kernel)
+        if (part) {
+          float* row = arow[f] + bs[f].c0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              const int c = bs[f].c0 + m;
-              if (c >= 0 && c < C) row[c] += A0 * bs[f].b[m] + A1 * bs[f].d1[m] + A2 * bs[f].d2[m];
-            }
+          for (int m = 0; m < 4; ++m) row[m] += A0 * bs[f].b[m] + A1 * bs[f].d1[m] + A2 * bs[f].d2[m];
+          arow[f][C + 3] += A0 * av[f].f0 + A1 * av[f].f1 + A2 * av[f].f2;
+        }
+        if (ga && live[f]) {
+          float out[J];
+          out[0] = A0 * ph1[f] + A1 * ph2[f] + A2 * ph3[f];
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            float v = gy[1 + d] * ph1[f];
+            if (d < D2) v += 2.0f * jet[f][1 + d] * gy[1 + D + d] * ph2[f];
+            out[1 + d] = v;
           }
-          if (ga) {
-            float* dst = ga + (p * I + i) * J;
-            float out[J];
-            out[0] = A0 * ph1[f] + A1 * ph2[f] + A2 * ph3[f];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-              float v = gy[1 + d] * ph1[f];
-              if (d < D2) v += 2.0f * jet[f][1 + d] * gy[1 + D + d] * ph2[f];
-              out[1 + d] = v;
-            }
+          for (int d = 0; d < D2; ++d) out[1 + D + d] = gy[1 + D + d] * ph1[f];
 #pragma unroll
-            for (int d = 0; d < D2; ++d) out[1 + D + d] = gy[1 + D + d] * ph1[f];
+          for (int j = 0; j < J; ++j) dst_row[joff[f] + j] = out[j];
 #pragma unroll
-            for (int j = 0; j < J; ++j) dst[j] = out[j];
-#pragma unroll
-            for (int j = 0; j < J; ++j) gmax[j] = fmaxf(gmax[j], fabsf(out[j]));
-          }
+          for (int j = 0; j < J; ++j) absmax_into(gmax[j], out[j]);
         }
       }
     }
@@ -170,8 +197,10 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   if (part) {
     float* dst = part + (size_t)blockIdx.x * I * C1;
     for (int t = threadIdx.x; t < I * C1; t += blockDim.x) {
+      const int i = t / C1, c = t - i * C1;
+      const int src = i * CP + (c < C ? c + 3 : C + 6);
       float s = 0.0f;
-      for (int w = 0; w < nw; ++w) s += s_acc[w * I * C1 + t];
+      for (int w = 0; w < nw; ++w) s += s_acc[w * tab + src];
       dst[t] = s;
     }
   }
@@ -182,17 +211,19 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   }
 }
 
+static size_t head_table_bytes(const LayerView& L) { return (size_t)(L.I + 1) * (L.C() + 7) * 4; }
+
 static int head_waves(const LayerView& L) {
-  const size_t table = (size_t)L.I * L.C1() * 4;
-  if (table * 4 <= 48 * 1024) return 4;
+  const size_t table = head_table_bytes(L);
+  if (table * 4 <= 64 * 1024) return 4;
   if (table * 2 <= 64 * 1024) return 2;
   return 1;
 }
 
-// dynamic LDS of a block: knot rows (+ 1/h), the packed weights, one gradient table per wave, the waves' loss sums
+// dynamic LDS of a block: knot rows (+ 1/h), the padded weight rows, one gradient table per wave, the waves' loss sums
 static size_t head_lds_bytes(const LayerView& L) {
   const int nw = head_waves(L);
-  return ((size_t)L.I * (L.nk() + 1) + (size_t)L.I * L.C1() * (1 + nw) + nw) * 4;
+  return (size_t)L.I * (L.nk() + 1) * 4 + head_table_bytes(L) * (1 + nw) + (size_t)nw * 4;
 }
 
 constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup

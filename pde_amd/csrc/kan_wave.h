@@ -36,6 +36,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return sum_xor32(v);
 }
 
+// Sums of FOUR values over the 64 lanes for the price of little more than one: a swap of half-waves adds the two
+// halves of a and of b at once (a's sum ends up in lanes 0..31, b's in lanes 32..63), likewise c and d, a swap of
+// rows does the same with the two results, and the sums inside the rows of 16 lanes then finish all four together:
+// row 0 holds a's total, row 1 c's, row 2 b's, row 3 d's.  Each total is read back with v_readlane, so the
+// results are wave-uniform (scalar registers).
+__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {
+  const auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  const float sab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);
+  const float scd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  const int vi = (int)__float_as_uint(v);
+  a = __uint_as_float((unsigned)__builtin_amdgcn_readlane(vi, 0));
+  c = __uint_as_float((unsigned)__builtin_amdgcn_readlane(vi, 16));
+  b = __uint_as_float((unsigned)__builtin_amdgcn_readlane(vi, 32));
+  d = __uint_as_float((unsigned)__builtin_amdgcn_readlane(vi, 48));
+}
+
+// m = max(m, |x|) in one instruction (fmaxf(m, fabsf(x)) costs a second one that quiets NaNs)
+__device__ __forceinline__ void absmax_into(float& m, float x) {
+  asm("v_max_f32 %0, %0, |%1|" : "+v"(m) : "v"(x));
+}
+
 // Per-jet maxima for the scales of the fp16 matrix kernels (kan_f16.hip): this lane's maxima of |value| per jet
 // slot -> maximum over the wave -> one integer atomic max per slot into out[0..3].  Non-negative floats order like
 // their bit patterns, and a maximum does not depend on the order of the atomics: results stay reproducible.
