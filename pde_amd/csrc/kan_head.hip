@@ -24,15 +24,20 @@ namespace pdekan {
 // spline columns (so the 4 live columns c0..c0+3, c0 in [-3, C-1] + what a row of knots allows, are always inside
 // the row and need no masking: the pads hold zero weights and collect sums nobody reads), then the base column.
 // Row I (all zero) serves the lanes past the last feature.
-__device__ __forceinline__ int head_row_words(int C) { return C + 7; }
+// Row lengths are odd: lane i works on row i, and rows an even number of words apart put lanes 16 (or 32) apart on
+// the same LDS bank.
+__host__ __device__ __forceinline__ int head_row_words(int C) { return (C + 7) | 1; }
+__host__ __device__ __forceinline__ int head_knot_words(int nk) { return nk + 1; }   // (odd here too would cost the fifth block per compute unit at 64 inputs)
 
-template <int D, int D2, int NF>
+// ACT: the layer's base activation, a compile-time constant (a run-time kind costs the SiLU arithmetic on every
+// point of an identity-activation head, selected away afterwards)
+template <int D, int D2, int NF, int ACT>
 __global__ void __launch_bounds__(256)
 head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
                const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ ginfo,
                const float* __restrict__ wp,
                float sigma, float rate, float inv_n, float* __restrict__ res_out, float* __restrict__ ga,
-               float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G, int act,
+               float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I, int G,
                unsigned* __restrict__ cot_out) {
   constexpr int J = 1 + D + D2;
   static_assert(D2 == D - 1, "assets first, time last");
@@ -40,7 +45,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1, CP = head_row_words(C);
   const int nw = blockDim.x >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int kr = nk + 1;                                  // knots + the feature's 1/h (0 = not equally spaced)
+  const int kr = head_knot_words(nk);                     // knots + the feature's 1/h (0 = not equally spaced) [+ pad]
   const int tab = (I + 1) * CP;
   float* s_knots = reinterpret_cast<float*>(smem);        // [I][kr]
   float* s_w = s_knots + I * kr;                          // [I+1][CP]
@@ -49,7 +54,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
 
   for (int t = threadIdx.x; t < I * kr; t += blockDim.x) {
     const int f = t / kr, k = t - f * kr;
-    s_knots[t] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
+    s_knots[t] = (k < nk) ? grid[(size_t)f * nk + k] : ((k == nk && ginfo) ? ginfo[f] : 0.0f);
   }
   for (int t = threadIdx.x; t < tab; t += blockDim.x) {
     const int i = t / CP, k = t - i * CP;
@@ -130,7 +135,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
     for (int f = 0; f < NF; ++f) {
       if (invh[f] > 0.0f) eval_basis_uniform_oneshot<true>(krow[f], nk, g0[f], glast[f], invh[f], jet[f][0], bs[f]);
       else eval_basis<true>(krow[f], nk, jet[f][0], bs[f]);
-      av[f] = eval_act(act, jet[f][0]);
+      av[f] = eval_act(ACT, jet[f][0]);
       const float* w = wrow[f] + bs[f].c0;
       const float wb = wbase[f];
       float p0 = wb * av[f].f0, p1 = wb * av[f].f1, p2 = wb * av[f].f2, p3 = wb * av[f].f3;
@@ -211,7 +216,7 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   }
 }
 
-static size_t head_table_bytes(const LayerView& L) { return (size_t)(L.I + 1) * (L.C() + 7) * 4; }
+static size_t head_table_bytes(const LayerView& L) { return (size_t)(L.I + 1) * head_row_words(L.C()) * 4; }
 
 static int head_waves(const LayerView& L) {
   const size_t table = head_table_bytes(L);
@@ -223,7 +228,7 @@ static int head_waves(const LayerView& L) {
 // dynamic LDS of a block: knot rows (+ 1/h), the padded weight rows, one gradient table per wave, the waves' loss sums
 static size_t head_lds_bytes(const LayerView& L) {
   const int nw = head_waves(L);
-  return (size_t)L.I * (L.nk() + 1) * 4 + head_table_bytes(L) * (1 + nw) + (size_t)nw * 4;
+  return (size_t)L.I * head_knot_words(L.nk()) * 4 + head_table_bytes(L) * (1 + nw) + (size_t)nw * 4;
 }
 
 constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup
@@ -242,26 +247,34 @@ int head_blocks(int64_t N, const LayerView& L) {
   return (int)b;
 }
 
-template <int D, int D2, int NF>
+template <int D, int D2, int NF, int ACT>
 static void head_launch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                         const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                         float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
   const int nw = head_waves(L);
   const size_t lds = head_lds_bytes(L);
-  auto k = head_bs_kernel<D, D2, NF>;
+  auto k = head_bs_kernel<D, D2, NF, ACT>;
   if (lds > 48 * 1024)
     ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
   k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, L.ginfo, wp, sigma, rate, inv_n, res, ga, part, loss_part,
-                                   N, L.I, L.G, L.act, cot_out);
+                                   N, L.I, L.G, cot_out);
+}
+
+template <int D, int D2, int NF>
+static void head_act(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
+                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
+                     float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
+  if (L.act == kActSiLU) head_launch<D, D2, NF, kActSiLU>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else head_launch<D, D2, NF, kActIdentity>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
 }
 
 template <int D, int D2>
 static void head_dispatch(const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                           const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                           float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
-  if (L.I <= 64) head_launch<D, D2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
-  else if (L.I <= 128) head_launch<D, D2, 2>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
-  else head_launch<D, D2, 4>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  if (L.I <= 64) head_act<D, D2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else if (L.I <= 128) head_act<D, D2, 2>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
+  else head_act<D, D2, 4>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
 }
 
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,

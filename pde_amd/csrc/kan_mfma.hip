@@ -701,9 +701,9 @@ bwd_weight_bf16x3_kernel(const float4* __restrict__ a, const float4* __restrict_
 // wave owns ALL columns x 64 outputs and the 4 waves of a block split the
 // points instead (8 per pass and wave, no block barrier inside the loop); their
 // accumulators are added through LDS at the end.  The E tile is built as in the
-// kernel above; the gY operand needs no LDS: in the 16x16x4 B layout lane
-// (n = lane&15, k = lane>>4) wants gY[point][output n][jet k], and a wave's 64
-// such dwords are 256 contiguous bytes of gy.
+// kernel above; the gY operand needs no LDS: the 16x16x4 instruction contracts
+// over 4 points of one jet slot, so the B operands of a lane (n = lane&15,
+// k = lane>>4) for the four slots are the 16 bytes gY[point k][output n][0..3].
 // Output: part[chunk][O][KI][C1].
 // ==========================================================================
 template <int C1, int KI>
@@ -741,24 +741,31 @@ bwd_weight_mfma_skinny_kernel(const float4* __restrict__ a, const float* __restr
 
   const int64_t pbeg = (int64_t)blockIdx.x * chunk_pts;
   const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
-  const int loff = (o0 + l15) * 4 + q;                   // this lane's dword inside a point's row of gy
+  // The matrix instruction contracts over 4 POINTS for one jet slot at a time: lane (n = lane&15, k = lane>>4)
+  // supplies gY[point 4*t4 + k][output n][jet j] for B and E[column n][point 4*t4 + k][jet j] for A, j = 0..3 in
+  // four instructions.  The four B operands of a lane are then one 16-byte load (all jets of one output of one
+  // point) and the four A operands one 16-byte LDS read.
+  const int loff = (q * O + o0 + l15) * 4;               // this lane's first float inside a group of 4 point rows of gy
 
-  float bA[PB][4], bB[PB][4];
+  f32x4 bA[2][4], bB[2][4];                              // [group of 4 points][output tile]
   float4 jet = make_float4(0.f, 0.f, 0.f, 0.f);
   // (PBASE is wave-uniform: row addresses are scalar, only `loff` is per lane)
 #define PDEKAN_SKINNY_FETCH(BUF, PBASE)                                                  \
   {                                                                                      \
     if ((PBASE) + PB <= pend) {                                                          \
-      _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                   \
-        const float* row = gy + (size_t)((PBASE) + t) * O * 4;                           \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) BUF[t][m] = row[loff + m * 64];    \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                    \
+        const float* row = gy + (size_t)((PBASE) + 4 * t) * O * 4;                       \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                    \
+          BUF[t][m] = *reinterpret_cast<const f32x4*>(row + loff + m * 64);              \
       }                                                                                  \
     } else {                                                                             \
-      _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                   \
-        const int64_t pp = (PBASE) + t;                                                  \
-        const bool in = pp < pend;                                                       \
-        const float* row = gy + (size_t)(in ? pp : pbeg) * O * 4;                        \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) BUF[t][m] = in ? row[loff + m * 64] : 0.0f; \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                    \
+        const bool in = (PBASE) + 4 * t + q < pend;                                      \
+        const float* row = gy + ((size_t)(in ? (PBASE) + 4 * t + q : pbeg) * O + o0 + l15) * 4; \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                  \
+          const f32x4 v = *reinterpret_cast<const f32x4*>(row + m * 64);                 \
+          BUF[t][m] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                              \
+        }                                                                                \
       }                                                                                  \
     }                                                                                    \
     if (gen_lane) {                                                                      \
@@ -776,12 +783,14 @@ bwd_weight_mfma_skinny_kernel(const float4* __restrict__ a, const float* __restr
       write_expanded<C1>(tileE, RS, f_local, p_local, e, c0, prev_c0, tileE + (f_local * C1) * RS + ROWS); \
     }                                                                                                  \
     PDEKAN_SKINNY_FETCH(BNEXT, (PBASE) + 4 * PB)                                                       \
-    _Pragma("unroll") for (int t = 0; t < PB; ++t) {                                                   \
-      float fe[NT];                                                                                    \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n) fe[n] = tileE[(n * 16 + l15) * RS + 4 * t + q];   \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                    \
+      f32x4 fe[NT];                                                                                    \
       _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                   \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                  \
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fe[n], BUF[t][m], acc[n][m], 0, 0, 0);      \
+        fe[n] = *reinterpret_cast<const f32x4*>(tileE + (n * 16 + l15) * RS + 16 * t + 4 * q);         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
+          _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                \
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fe[n][j], BUF[t][m][j], acc[n][m], 0, 0, 0); \
     }                                                                                                  \
   }
   // wave w takes passes w, w+4, w+8, ... of the block's chunk, two per loop trip (register ping-pong)

@@ -206,6 +206,94 @@ __device__ __forceinline__ void jets_stage(float* sJ, const float* a, const Wave
                                      (__attribute__((address_space(3))) void*)(sJ + 64 * k * 4), 16, 0, 0);
 }
 
+// One feature of one point into the lane's 32 outputs x 4 jets: the expanded jets of the 4 live splines and of the
+// base column times the outputs' weights.  tb = the lane's first output's window slot (or raw-row position) in the
+// feature's table, bb = its base weights.
+template <int RS>
+__device__ __forceinline__ void feature_into_outputs(f32x2 (&accl)[32], f32x2 (&acch)[32], const Live& L, const f32x4& cur,
+                                                     const float* tb, const float* bb) {
+  const float s2 = cur[1] * cur[1];
+  f32x2 el[5], eh[5];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    el[m] = (f32x2){L.b[m], L.d1[m] * cur[1]};
+    eh[m] = (f32x2){L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
+  }
+  el[4] = (f32x2){L.act.f0, L.act.f1 * cur[1]};
+  eh[4] = (f32x2){L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
+  // outputs in groups of 4; the weights of group q+2 are read from LDS while group q is consumed
+  f32x4 wq[3][4], bq[3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wq[r][k] = live_weights<RS>(tb + (r * 4 + k) * RS);
+    bq[r] = *reinterpret_cast<const f32x4*>(bb + r * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int cq = q % 3, nxt = (q + 2) % 3;
+    if (q + 2 < 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wq[nxt][k] = live_weights<RS>(tb + ((q + 2) * 4 + k) * RS);
+      bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 2) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x2 w01 = lo2(wq[cq][k]), w23 = hi2(wq[cq][k]);
+      const f32x2 wb = (k < 2) ? lo2(bq[cq]) : hi2(bq[cq]);
+      f32x2& tl = accl[q * 4 + k];
+      f32x2& th = acch[q * 4 + k];
+      pkfma_x(tl, el[0], w01); pkfma_x(th, eh[0], w01);
+      pkfma_y(tl, el[1], w01); pkfma_y(th, eh[1], w01);
+      pkfma_x(tl, el[2], w23); pkfma_x(th, eh[2], w23);
+      pkfma_y(tl, el[3], w23); pkfma_y(th, eh[3], w23);
+      if (k & 1) { pkfma_y(tl, el[4], wb); pkfma_y(th, eh[4], wb); }
+      else       { pkfma_x(tl, el[4], wb); pkfma_x(th, eh[4], wb); }
+    }
+  }
+}
+
+// A lane holds 32 outputs x 4 jets of one point (512 contiguous bytes in y).  Stored straight from registers every
+// instruction would touch 64 different lines 16 bytes at a time, so the wave's tile goes through its own LDS area
+// (64 lines of kParkLine floats) 8 outputs at a time and leaves as whole 128-byte lines (8 lanes per line).
+constexpr int kParkLine = 36;                            // floats per parked line: 32 + 4 pad (bank spread)
+// FULL: every point of the tile is live; the stores are then unconditional, which keeps the epilogue one basic block
+// (with branches around the stores the compiler can no longer count them and waits for ALL of them wherever the
+// code behind needs an earlier load).
+template <int OG, bool FULL = false>
+__device__ __forceinline__ void store_outputs_through_lds(float* park, const f32x2 (&accl)[32], const f32x2 (&acch)[32],
+                                                          float* __restrict__ ytile, int nlive, int OT, int o0,
+                                                          int lane, int g, int pl) {   // ytile = row of the tile's first point
+  static_assert(8 % OG == 0, "a pass of 8 lines is whole points");
+  const int line_w = pl * OG + g;                        // the line this lane fills: (point, output group)
+  // the line this lane stores in pass r is (lane >> 3) + 8r: point row0 + (8/OG) r, always the same output group;
+  // everything that changes with r or k is wave-uniform and goes into the scalar part of the address
+  const int row0 = (lane >> 3) / OG;
+  const int lane_off = (row0 * OT + o0 + ((lane >> 3) % OG) * 32 + (lane & 7)) * 4;
+  const float* rd = park + (lane >> 3) * kParkLine + (lane & 7) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = 8 * k + j;
+      *reinterpret_cast<f32x4*>(park + line_w * kParkLine + j * 4) = (f32x4){accl[o][0], accl[o][1], acch[o][0], acch[o][1]};
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(rd + 8 * r * kParkLine);
+      float* yr = ytile + ((size_t)(r * (8 / OG)) * OT + 8 * k) * 4;
+      if (FULL || row0 + r * (8 / OG) < nlive) *reinterpret_cast<f32x4*>(yr + lane_off) = v;
+    }
+  }
+}
+
+// live points of a tile of PW points that starts at P0
+__device__ __forceinline__ int tile_live(int64_t P0, int64_t N, int PW) {
+  const int64_t left = N - P0;
+  return left <= 0 ? 0 : (left < PW ? (int)left : PW);
+}
+
 // ==========================================================================
 // forward
 // ==========================================================================
@@ -262,49 +350,8 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
       table_stage<O, RS>(sT + (buf ^ 1) * O * RS, sB + (buf ^ 1) * O, win, wbt, i + 1, wave, lane, OT, o0);
     if ((i % FS) == 0 && i + FS < I)     // features i+4..i+7 into the other staging buffer
       jets_stage<PW, FS>(sJw + (((i / FS) + 1) & 1) * PW * FS * 4, a, wr, I, i + FS);
-    const float s2 = cur[1] * cur[1];
-    // expanded jets of the 4 live splines and of the base column
-    f32x2 el[5], eh[5];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      el[m] = (f32x2){L.b[m], L.d1[m] * cur[1]};
-      eh[m] = (f32x2){L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
-    }
-    el[4] = (f32x2){L.act.f0, L.act.f1 * cur[1]};
-    eh[4] = (f32x2){L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
-    const float* tb = sT + buf * O * RS + (g * 32) * RS + L.slot * (RS == 64 ? 4 : 1);
-    const float* bb = sB + buf * O + g * 32;
-    // outputs in groups of 4; the weights of group q+2 are read from LDS while group q is consumed
-    f32x4 wq[3][4], bq[3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) wq[r][k] = live_weights<RS>(tb + (r * 4 + k) * RS);
-      bq[r] = *reinterpret_cast<const f32x4*>(bb + r * 4);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int cq = q % 3, nxt = (q + 2) % 3;
-      if (q + 2 < 8) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wq[nxt][k] = live_weights<RS>(tb + ((q + 2) * 4 + k) * RS);
-        bq[nxt] = *reinterpret_cast<const f32x4*>(bb + (q + 2) * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x2 w01 = lo2(wq[cq][k]), w23 = hi2(wq[cq][k]);
-        const f32x2 wb = (k < 2) ? lo2(bq[cq]) : hi2(bq[cq]);
-        f32x2& tl = accl[q * 4 + k];
-        f32x2& th = acch[q * 4 + k];
-        pkfma_x(tl, el[0], w01); pkfma_x(th, eh[0], w01);
-        pkfma_y(tl, el[1], w01); pkfma_y(th, eh[1], w01);
-        pkfma_x(tl, el[2], w23); pkfma_x(th, eh[2], w23);
-        pkfma_y(tl, el[3], w23); pkfma_y(th, eh[3], w23);
-        if (k & 1) { pkfma_y(tl, el[4], wb); pkfma_y(th, eh[4], wb); }
-        else       { pkfma_x(tl, el[4], wb); pkfma_x(th, eh[4], wb); }
-      }
-    }
+    feature_into_outputs<RS>(accl, acch, L, cur, sT + buf * O * RS + (g * 32) * RS + L.slot * (RS == 64 ? 4 : 1),
+                             sB + buf * O + g * 32);
     if (i + 1 < I) {
       const int n = i + 1;
       cur = *reinterpret_cast<const f32x4*>(sJw + (((n / FS) & 1) * PW * FS + pl * FS + (n % FS)) * 4);
@@ -323,30 +370,193 @@ fwd_sparse_kernel(const float* __restrict__ a, const float* __restrict__ grid, c
     }
     publish_jet_absmax(ml[0], ml[1], mh[0], mh[1], amax_out);
   }
-  // Epilogue: a lane holds 32 outputs x 4 jets of one point (512 contiguous bytes in y).  Stored
-  // straight from registers every instruction would touch 64 different lines 16 bytes at a time, so the
-  // tile goes through LDS 8 outputs at a time and leaves as whole 128-byte lines (8 lanes per line).
+  // Epilogue through LDS (store_outputs_through_lds): each wave's area spans sT, sB and sJ (raw rows: also the head
+  // of the knot rows, dead by now; the launcher sizes the allocation for it)
   __syncthreads();                                       // every wave is done with the tables
-  constexpr int LS = 36;                                 // floats per parked line: 32 + 4 pad (bank spread)
-  float* park = sT + wave * (64 * LS);                   // 64 lines per wave and pass; spans sT, sB and sJ
-  // (raw rows: also the head of the knot rows, dead by now; the launcher sizes the allocation for it)
-  static_assert(RS != 64 || 4 * 64 * LS <= 2 * O * 64 + 2 * O + 4 * 2 * PW * FS * 4, "parking area fits the staging buffers");
-  const int line_w = pl * OG + g;                        // the line this lane fills: (point, output group)
+  static_assert(RS != 64 || 4 * 64 * kParkLine <= 2 * O * 64 + 2 * O + 4 * 2 * PW * FS * 4, "parking area fits the staging buffers");
+  store_outputs_through_lds<OG>(sT + wave * (64 * kParkLine), accl, acch, y + P0 * OT * 4, wr.nlive, OT, o0, lane, g, pl);
+}
+
+// ==========================================================================
+// forward of a layer with ONE or TWO inputs (the first layer of a PINN on (S, t)).  With so few features there is
+// little arithmetic per output byte and the mapping above (a lane keeps 32 outputs x 4 jets of a point) spends its
+// time moving results through LDS to get whole lines out, two waves per SIMD.  Here
+//   * one block of 16 waves per compute unit stages the tables of ALL the layer's features once and stays: each
+//     wave then walks over batches of 32 points on its own (no block barrier after the prologue);
+//   * a batch is evaluated once: lane = one (point, feature), which leaves the 5 expanded jets of that pair and its
+//     interval slot in the wave's LDS area;
+//   * the products run 8 points at a time with lane = (point, output mod 8): the lane's 8 outputs oc, oc+8, ... are
+//     32 accumulator registers, the pair's jets are broadcast reads, and for every j the 8 lanes of a point hold
+//     outputs 8j..8j+7, so each store instruction writes 8 whole 128-byte lines straight from registers.
+// Table rows are 68 floats apart in LDS (not 64): the 8 output rows a 16-byte read touches land on different banks.
+// With its stores switched off the kernel runs in half the time: what bounds it is writing N x O x 16 bytes.
+// ==========================================================================
+constexpr int kFewInputsMax = 2;
+constexpr int kFewRow = 68;                  // floats per (feature, output) row of the staged window tables
+constexpr int kFewPair = 20;                 // floats per evaluated (point, feature): 5 columns x 4 jets
+constexpr int kFewBatch = 32;                // points per wave and batch
+constexpr int kFewWaves = 16;
+
+__device__ __forceinline__ void absmax3_into(float& m, float a, float b) {   // m = max(m, |a|, |b|)
+  asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+}
+
+// the 4 steps of 8 points of one batch; FULL: all 32 points live (unconditional stores: one basic block, so the
+// compiler can count the stores that follow the loads of the next batch's jets instead of waiting for all of them)
+template <bool FULL>
+__device__ __forceinline__ void few_inputs_products(const float* stg, const int* stg_slot, const float* sT, const float* sB,
+                                                    float* __restrict__ ytile, int nlive, int I, int OT, int o0, int lane,
+                                                    float (&amax)[4], bool want_amax, const f32x4& touch) {
+  const int pl = lane >> 3, oc = lane & 7;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int st = 0; st < kFewBatch / 8; ++st) {
+    const int pt = st * 8 + pl;
+    f32x2 tl[8], th[8];                      // jets (0,1) and (2,3) of outputs oc + 8j
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int o = 8 * k + j;
-      *reinterpret_cast<f32x4*>(park + line_w * LS + j * 4) = (f32x4){accl[o][0], accl[o][1], acch[o][0], acch[o][1]};
+    for (int j = 0; j < 8; ++j) { tl[j] = (f32x2){0.f, 0.f}; th[j] = (f32x2){0.f, 0.f}; }
+#pragma unroll
+    for (int f = 0; f < kFewInputsMax; ++f) {
+      if (f < I) {
+        const float* e = stg + (pt * I + f) * kFewPair;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(e), e1 = *reinterpret_cast<const f32x4*>(e + 4),
+                    e2 = *reinterpret_cast<const f32x4*>(e + 8), e3 = *reinterpret_cast<const f32x4*>(e + 12),
+                    e4 = *reinterpret_cast<const f32x4*>(e + 16);
+        const int slot = stg_slot[pt * I + f];
+        const float* tb = sT + (f * 64 + oc) * kFewRow + slot * 4;
+        const f32x4 bw0 = *reinterpret_cast<const f32x4*>(sB + f * 64 + oc * 8);
+        const f32x4 bw1 = *reinterpret_cast<const f32x4*>(sB + f * 64 + oc * 8 + 4);
+        // e0 = (el0, el1), e1 = (el2, el3), e2 = (el4, eh0), e3 = (eh1, eh2), e4 = (eh3, eh4)
+        const f32x2 el0 = lo2(e0), el1 = hi2(e0), el2 = lo2(e1), el3 = hi2(e1), el4 = lo2(e2);
+        const f32x2 eh0 = hi2(e2), eh1 = lo2(e3), eh2 = hi2(e3), eh3 = lo2(e4), eh4 = hi2(e4);
+        // (weights 4 outputs at a time: with four waves per SIMD the LDS latency hides behind the other waves, and
+        // all 8 in flight at once do not fit the 128 registers a wave has)
+        f32x4 w[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f32x4*>(tb + 8 * j * kFewRow);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j == 4) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 4; jj < 8; ++jj) w[jj] = *reinterpret_cast<const f32x4*>(tb + 8 * jj * kFewRow);
+          }
+          const f32x2 w01 = lo2(w[j]), w23 = hi2(w[j]);
+          const f32x4 bw = j < 4 ? bw0 : bw1;
+          const f32x2 wb = (j & 2) ? hi2(bw) : lo2(bw);
+          pkfma_x(tl[j], el0, w01); pkfma_x(th[j], eh0, w01);
+          pkfma_y(tl[j], el1, w01); pkfma_y(th[j], eh1, w01);
+          pkfma_x(tl[j], el2, w23); pkfma_x(th[j], eh2, w23);
+          pkfma_y(tl[j], el3, w23); pkfma_y(th[j], eh3, w23);
+          if (j & 1) { pkfma_y(tl[j], el4, wb); pkfma_y(th[j], eh4, wb); }
+          else       { pkfma_x(tl[j], el4, wb); pkfma_x(th[j], eh4, wb); }
+        }
+      }
     }
+    if (want_amax && (FULL || pt < nlive)) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int line = (lane >> 3) + 8 * r, j = lane & 7;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(park + line * LS + j * 4);
-      const int64_t pp = P0 + line / OG;
-      if (pp < N) *reinterpret_cast<f32x4*>(y + (pp * OT + o0 + (line % OG) * 32 + 8 * k + j) * 4) = v;
+      for (int j = 0; j < 8; j += 2) {
+        absmax3_into(amax[0], tl[j][0], tl[j + 1][0]); absmax3_into(amax[1], tl[j][1], tl[j + 1][1]);
+        absmax3_into(amax[2], th[j][0], th[j + 1][0]); absmax3_into(amax[3], th[j][1], th[j + 1][1]);
+      }
+    }
+    // Loads and stores retire in one order: a wait for the next batch's jets placed behind this batch's stores is a
+    // wait for the stores to reach memory.  Touching the jets before the second half of the stores puts the wait
+    // there, most of a batch of arithmetic after the loads went out.
+    if (st == kFewBatch / 8 - 2) asm volatile("" :: "v"(touch));
+    float* dst = ytile + (pt * OT + o0 + oc) * 4;
+    if (FULL || pt < nlive) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<f32x4*>(dst + j * 32) = (f32x4){tl[j][0], tl[j][1], th[j][0], th[j][1]};
     }
   }
+}
+
+__global__ void __launch_bounds__(64 * kFewWaves, 1)
+fwd_sparse_few_inputs_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                             const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ y, int64_t N,
+                             int I, int G, int act, int OT, int skip_near_uniform, unsigned* __restrict__ amax_out) {
+  if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
+  const int o0 = (int)blockIdx.y * 64;
+  const int nk = G + 7;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = reinterpret_cast<float*>(smem);            // [I][64][kFewRow]
+  float* sB = sT + kFewInputsMax * 64 * kFewRow;         // [I][8 (output mod 8)][8 (output / 8)]
+  float* sK = sB + kFewInputsMax * 64;                   // [I][kKnotPadS]
+  float* sE = sK + kFewInputsMax * kKnotPadS;            // [16 waves][64 pairs][kFewPair], then [16 waves][64] slots
+  int* sS = reinterpret_cast<int*>(sE + kFewWaves * 64 * kFewPair);
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int t = tid; t < I * (nk + 1); t += 64 * kFewWaves) {   // knot rows + the feature's 1/h (0 = not equally spaced)
+    const int f = t / (nk + 1), k = t - f * (nk + 1);
+    sK[f * kKnotPadS + k] = (k < nk) ? grid[(size_t)f * nk + k] : (ginfo ? ginfo[f] : 0.0f);
+  }
+  for (int t = tid; t < I * 64 * 16; t += 64 * kFewWaves) {    // window tables, 16 bytes at a time
+    const int i = t >> 10, r = (t >> 4) & 63, c = t & 15;
+    *reinterpret_cast<f32x4*>(sT + (i * 64 + r) * kFewRow + c * 4) =
+        *reinterpret_cast<const f32x4*>(win + ((size_t)(i * OT + o0 + r) * 64 + c * 4));
+  }
+  for (int t = tid; t < I * 64; t += 64 * kFewWaves) {
+    const int i = t >> 6, o = t & 63;
+    sB[i * 64 + (o & 7) * 8 + (o >> 3)] = wbt[(size_t)i * OT + o0 + o];
+  }
+  __syncthreads();
+
+  float* stg = sE + wave * (64 * kFewPair);
+  int* stg_slot = sS + wave * 64;
+  // evaluation: lane = pair (point, feature) of the batch
+  const int ept = (I == 2) ? (lane >> 1) : lane, ef = (I == 2) ? (lane & 1) : 0;
+  const bool eval_lane = ept < kFewBatch;
+  // a block walks a contiguous range of batches, its waves side by side: what the chip writes at any moment is then
+  // one compact window per block (16 x 32 KiB), not single batches spread over the whole tensor
+  const int64_t nbatch_all = (N + kFewBatch - 1) / kFewBatch;
+  const int64_t per_block = (nbatch_all + gridDim.x - 1) / gridDim.x;
+  const int64_t bfirst = (int64_t)blockIdx.x * per_block;
+  const int64_t nbatch = (bfirst + per_block < nbatch_all) ? bfirst + per_block : nbatch_all;
+  const int64_t bstride = kFewWaves;
+  int64_t b = bfirst + wave;
+  float amax[4] = {0.f, 0.f, 0.f, 0.f};                  // per-jet maxima of the outputs this lane produced
+  // jets of a batch: a wave-uniform row address (the batch's first point, or the last point of all for a batch past
+  // the end) plus a 32-bit offset per lane
+  f32x4 nxt;
+#define PDEKAN_FEW_FETCH(B)                                                                          \
+  {                                                                                                  \
+    const int nl_ = tile_live((B) * kFewBatch, N, kFewBatch);                                        \
+    const float* row_ = a + (nl_ > 0 ? (B) * kFewBatch : N - 1) * I * 4;                             \
+    const int r_ = (nl_ > 0 && eval_lane) ? (ept < nl_ ? ept : nl_ - 1) : 0;                         \
+    nxt = *reinterpret_cast<const f32x4*>(row_ + (r_ * I + ef) * 4);                                 \
+  }
+  PDEKAN_FEW_FETCH(b)
+  for (; b < nbatch; b += bstride) {
+    const int64_t P0 = b * kFewBatch;
+    const int nlive = tile_live(P0, N, kFewBatch);
+    const f32x4 cur = nxt;
+    PDEKAN_FEW_FETCH(b + bstride)
+    if (eval_lane) {
+      const Live L = eval_live<false>(sK + ef * kKnotPadS, nk, act, cur[0]);
+      const float s2 = cur[1] * cur[1];
+      f32x2 el[5], eh[5];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        el[m] = (f32x2){L.b[m], L.d1[m] * cur[1]};
+        eh[m] = (f32x2){L.d1[m] * cur[2], L.d2[m] * s2 + L.d1[m] * cur[3]};
+      }
+      el[4] = (f32x2){L.act.f0, L.act.f1 * cur[1]};
+      eh[4] = (f32x2){L.act.f1 * cur[2], L.act.f2 * s2 + L.act.f1 * cur[3]};
+      float* e = stg + lane * kFewPair;
+      *reinterpret_cast<f32x4*>(e) = (f32x4){el[0][0], el[0][1], el[1][0], el[1][1]};
+      *reinterpret_cast<f32x4*>(e + 4) = (f32x4){el[2][0], el[2][1], el[3][0], el[3][1]};
+      *reinterpret_cast<f32x4*>(e + 8) = (f32x4){el[4][0], el[4][1], eh[0][0], eh[0][1]};
+      *reinterpret_cast<f32x4*>(e + 12) = (f32x4){eh[1][0], eh[1][1], eh[2][0], eh[2][1]};
+      *reinterpret_cast<f32x4*>(e + 16) = (f32x4){eh[3][0], eh[3][1], eh[4][0], eh[4][1]};
+      stg_slot[lane] = L.slot;
+    }
+    float* ytile = y + P0 * OT * 4;
+    if (nlive == kFewBatch) few_inputs_products<true>(stg, stg_slot, sT, sB, ytile, nlive, I, OT, o0, lane, amax, amax_out != nullptr, nxt);
+    else few_inputs_products<false>(stg, stg_slot, sT, sB, ytile, nlive, I, OT, o0, lane, amax, amax_out != nullptr, nxt);
+  }
+#undef PDEKAN_FEW_FETCH
+  if (amax_out) publish_jet_absmax(amax[0], amax[1], amax[2], amax[3], amax_out);
 }
 
 // ==========================================================================
@@ -590,10 +800,35 @@ static void fwd_sparse_launch(const LayerView& L, const float* a, const float* w
   k<<<g, 256, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip, amax_out);
 }
 
+// one or two inputs, window tables: one resident block per compute unit (fwd_sparse_few_inputs_kernel)
+static bool few_inputs_layout(const LayerView& L) {
+  const char* off = getenv("PDEKAN_DISABLE_FEW_INPUTS");  // A/B switch
+  if (off && off[0] == '1') return false;
+  return window_layout(L) && L.I <= kFewInputsMax;
+}
+
+static void fwd_sparse_few_inputs_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N,
+                                         hipStream_t st, int skip, unsigned* amax_out) {
+  const float* wbt = win + (size_t)L.I * L.O * 64;
+  auto k = fwd_sparse_few_inputs_kernel;
+  const size_t lds = ((size_t)kFewInputsMax * 64 * kFewRow + kFewInputsMax * 64 + kFewInputsMax * kKnotPadS +
+                      (size_t)kFewWaves * 64 * kFewPair + kFewWaves * 64) * 4;
+  big_lds(k, lds);
+  const int64_t batches = (N + kFewBatch - 1) / kFewBatch;
+  int64_t blocks = (batches + kFewWaves - 1) / kFewWaves;
+  const int64_t resident = 256 / (L.O / 64);             // one block per compute unit
+  if (blocks > resident) blocks = resident;
+  if (blocks < 1) blocks = 1;
+  const dim3 g((unsigned)blocks, L.O / 64);
+  k<<<g, 64 * kFewWaves, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip, amax_out);
+}
+
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
                        bool skip_near_uniform, unsigned* amax_out) {
   const int skip = skip_near_uniform ? 1 : 0;
-  if (!window_layout(L)) {
+  if (few_inputs_layout(L)) {
+    fwd_sparse_few_inputs_launch(L, a, win, y, N, st, skip, amax_out);
+  } else if (!window_layout(L)) {
     fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st, skip, amax_out);
   } else if (L.O == 64) {
     if (L.I % 4 == 0) fwd_sparse_launch<64, 4>(L, a, win, y, N, st, skip, amax_out);
