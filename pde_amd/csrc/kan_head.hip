@@ -241,7 +241,8 @@ bool head_eligible(int D, const LayerView& L) {
 
 int head_blocks(int64_t N, const LayerView& L) {
   const int nw = head_waves(L);
-  int64_t b = (N + (int64_t)nw * 16 - 1) / ((int64_t)nw * 16);
+  // at least 4 points per wave (small batches are latency-bound: more, shorter blocks finish sooner)
+  int64_t b = (N + (int64_t)nw * 4 - 1) / ((int64_t)nw * 4);
   if (b > kHeadBlocksMax) b = kHeadBlocksMax;             // 5 blocks per CU: the register budget's limit
   if (b < 1) b = 1;
   return (int)b;

@@ -47,11 +47,16 @@ __global__ void grid_info_kernel(const float* __restrict__ grid, float* __restri
 // --------------------------------------------------------------------------
 // pack: parameters -> wp / wt
 // --------------------------------------------------------------------------
+// ginfo (or nullptr): the layer's knot-row classes are written by the same launch (what grid_info_kernel does)
 __global__ void pack_weights_kernel(const float* __restrict__ base_w, const float* __restrict__ spline_w,
                                     const float* __restrict__ scaler, float* __restrict__ wp,
-                                    float* __restrict__ wt, int I, int O, int C) {
+                                    float* __restrict__ wt, int I, int O, int C, const float* __restrict__ grid,
+                                    float* __restrict__ ginfo, int nk) {
   const int C1 = C + 1;
   const int total = O * I * C1;
+  if (ginfo)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < I; i += gridDim.x * blockDim.x)
+      ginfo[i] = knot_spacing_info(grid + (size_t)i * nk, nk);
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int c = t % C1;
     const int oi = t / C1;
@@ -654,11 +659,12 @@ void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st) {
   grid_info_kernel<<<(L.I + 63) / 64, 64, 0, st>>>(L.grid, ginfo, L.I, L.nk());
 }
 
-void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st) {
+// ginfo_out (or nullptr): also classify the layer's knot rows into it (launch_grid_info in the same launch)
+void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st, float* ginfo_out) {
   const int total = L.O * L.I * (L.C() + 1);
   const int blocks = (total + 255) / 256;
   pack_weights_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(L.base_w, L.spline_w, L.scaler, wp, wt,
-                                                                  L.I, L.O, L.C());
+                                                                  L.I, L.O, L.C(), L.grid, ginfo_out, L.nk());
 }
 
 template <int D, int D2>
@@ -728,7 +734,7 @@ int generic_weight_chunks(int64_t N, int I, int O) {
   const BwTile T = bw_tile(I, O);
   const int tiles = ((I + T.TI - 1) / T.TI) * ((O + T.TO - 1) / T.TO);
   int64_t want = (2048 + tiles - 1) / tiles;
-  const int64_t max_by_pts = (N + 511) / 512;
+  const int64_t max_by_pts = (N + 127) / 128;            // (small batches are latency-bound: short chunks finish sooner)
   if (want > max_by_pts) want = max_by_pts;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;

@@ -510,9 +510,8 @@ int pack_model(ModelPlan& P, const ModelWs& W, const ModelStats& S, hipStream_t 
   hipError_t e = hipMemsetAsync(S.base, 0, S.bytes(), st);
   if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "clearing the scale maxima: %s", hipGetErrorString(e));
   for (int l = 0; l < nl; ++l) {
-    pdekan::launch_grid_info(P.L[l], W.ginfo[l], st);
+    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st, W.ginfo[l]);   // knot-row classes in the same launch
     P.L[l].ginfo = W.ginfo[l];
-    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st);
     if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
     if (W.wpl[l]) {
       pdekan::launch_absmax(W.wp[l], (int64_t)P.L[l].packed_floats(), S.w(l), st);
