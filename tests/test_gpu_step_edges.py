@@ -295,3 +295,31 @@ def test_spline_orders_other_than_cubic(k):
     assert max_rel(xg.grad.cpu(), xr.grad) <= TOL
     for n_, p in lay.named_parameters():
         assert max_rel(p.grad.cpu(), p64[n_].grad) <= TOL, n_
+
+
+@pytest.mark.parametrize("widths,N", [([2, 64, 64, 1], 1), ([2, 64, 64, 1], 31), ([2, 64, 64, 1], 33),
+                                      ([2, 128, 64, 1], 4097), ([2, 64, 1], 100001)])
+def test_first_layer_kernel_for_two_inputs(widths, N, monkeypatch):
+    """A 2-input layer with window tables takes a kernel of its own (resident blocks, batches of 32 points, stores
+    straight from registers).  Batches with dead points, a single point, 128 outputs (two block columns) and more
+    batches than resident waves: same step as with that kernel switched off, and as the fp64 oracle."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, 10, 21)
+    x = torch.rand(N, 2, generator=torch.Generator().manual_seed(N))
+    ref64 = O.pinn_step(x.double(), O.layers_from_state_dict(m.state_dict(), dtype=torch.float64), "silu")
+    m = m.cuda()
+    step = BlackScholesStep(m)
+    res = torch.empty(N, device="cuda")
+    loss = step(x.cuda(), residual_out=res).item()
+    grad = step.flat_grad.clone()
+    monkeypatch.setenv("PDEKAN_DISABLE_FEW_INPUTS", "1")
+    res_b = torch.empty(N, device="cuda")
+    loss_b = step(x.cuda(), residual_out=res_b).item()
+    monkeypatch.delenv("PDEKAN_DISABLE_FEW_INPUTS")
+    assert max_rel(res.cpu(), res_b.cpu()) <= 2e-6
+    assert abs(loss - loss_b) <= 2e-6 * abs(loss_b)
+    assert max_rel(grad.cpu(), step.flat_grad.cpu()) <= 5e-6
+    flat64 = torch.cat([ref64["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in KEYS])
+    assert max_rel(res.cpu(), ref64["res"]) <= TOL
+    assert abs(loss - ref64["loss"].item()) <= TOL * abs(ref64["loss"].item())
+    assert max_rel(grad.cpu(), flat64) <= TOL
