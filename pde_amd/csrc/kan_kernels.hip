@@ -73,6 +73,43 @@ __global__ void pack_weights_kernel(const float* __restrict__ base_w, const floa
   }
 }
 
+// The same for up to kPackLayersMax layers of a model in ONE launch (blockIdx.y = layer), which also clears the
+// words at `clear` (the maxima the fp16 matrix kernels combine into): a step on 10^4 points is the sum of its launch
+// latencies, and every layer's pack used to be two launches plus a memset.
+struct PackLayer {
+  const float* base_w; const float* spline_w; const float* scaler; const float* grid;
+  float* wp; float* wt; float* ginfo;
+  int I, O, C, nk;
+};
+struct PackModelArgs {
+  PackLayer layer[kPackLayersMax];
+  unsigned* clear; int clear_words;
+};
+
+__global__ void pack_model_kernel(PackModelArgs args) {
+  const PackLayer L = args.layer[blockIdx.y];
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  if (blockIdx.y == 0)
+    for (int t = tid; t < args.clear_words; t += nth) args.clear[t] = 0u;
+  for (int i = tid; i < L.I; i += nth) L.ginfo[i] = knot_spacing_info(L.grid + (size_t)i * L.nk, L.nk);
+  const int C1 = L.C + 1;
+  const int total = L.O * L.I * C1;
+  for (int t = tid; t < total; t += nth) {
+    const int c = t % C1;
+    const int oi = t / C1;
+    const int i = oi % L.I, o = oi / L.I;
+    float v;
+    if (c < L.C) {
+      v = L.spline_w[(size_t)oi * L.C + c];
+      if (L.scaler) v *= L.scaler[oi];
+    } else {
+      v = L.base_w[oi];
+    }
+    L.wp[t] = v;
+    L.wt[(size_t)(i * C1 + c) * L.O + o] = v;
+  }
+}
+
 // --------------------------------------------------------------------------
 // seed: points x[N][d] (any strides) -> input jets a[N][d][J]
 // --------------------------------------------------------------------------
@@ -426,6 +463,66 @@ sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, f
 }
 
 // --------------------------------------------------------------------------
+// The two kernels below in one launch (C + 1 <= 64): a block takes 64 / (C+1) whole edges, adds their elements over
+// the chunks exactly as sum_partials_kernel does (same order, same result bit for bit) and unpacks them as
+// reduce_unpack_kernel does.  One launch less per layer and step.
+// --------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * kSumWaves)
+sum_unpack_kernel(const float* __restrict__ part, int nchunks, ChunkSelect sel, const float* __restrict__ spline_w,
+                  const float* __restrict__ scaler, float* __restrict__ g_base, float* __restrict__ g_spline,
+                  float* __restrict__ g_scaler, int I, int O, int C, int accumulate) {
+  __shared__ float s_r[kSumWaves][64];
+  __shared__ float s_sum[64];
+  const int C1 = C + 1, EB = 64 / C1, edges = O * I;
+  const size_t total = (size_t)edges * C1;
+  if (sel.ginfo) {                            // which run of chunks holds this call's partials: settled by the knot rows
+    const bool u = all_rows_near_uniform(sel.ginfo, sel.I);
+    part += (size_t)(u ? sel.first_uniform : sel.first_other) * total;
+    nchunks = u ? sel.n_uniform : sel.n_other;
+  }
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int el = lane / C1, c = lane - el * C1;            // edge inside the block, column
+  const int edge = blockIdx.x * EB + el;
+  const bool live = el < EB && edge < edges;
+  const size_t e = (size_t)edge * C1 + c;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (live) {
+    int k = g;
+    for (; k + 3 * kSumWaves < nchunks; k += 4 * kSumWaves) {
+      s0 += part[(size_t)k * total + e];
+      s1 += part[(size_t)(k + kSumWaves) * total + e];
+      s2 += part[(size_t)(k + 2 * kSumWaves) * total + e];
+      s3 += part[(size_t)(k + 3 * kSumWaves) * total + e];
+    }
+    for (; k < nchunks; k += kSumWaves) s0 += part[(size_t)k * total + e];
+  }
+  s_r[g][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0) return;                          // (no barrier below: the rest is wave 0 on its own)
+  float sum = 0.0f;
+#pragma unroll
+  for (int w = 0; w < kSumWaves; ++w) sum += s_r[w][lane];
+  s_sum[lane] = sum;
+  if (live) {
+    if (c < C) {
+      const float v = sum * (scaler ? scaler[edge] : 1.0f);
+      float* dst = g_spline + (size_t)edge * C + c;
+      *dst = accumulate ? (*dst + v) : v;
+    } else {
+      g_base[edge] = accumulate ? (g_base[edge] + sum) : sum;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (live && c == 0 && g_scaler) {
+    float gs = 0.0f;
+    for (int cc = 0; cc < C; ++cc) gs += s_sum[el * C1 + cc] * spline_w[(size_t)edge * C + cc];
+    g_scaler[edge] = accumulate ? (g_scaler[edge] + gs) : gs;
+  }
+}
+
+// --------------------------------------------------------------------------
 // sum the per-chunk partials in chunk order and unpack to parameter gradients:
 //   g_base[o][i]      = gW[o][i][C]
 //   g_spline[o][i][c] = gW[o][i][c] * scaler[o][i]           (scaler present)
@@ -667,6 +764,26 @@ void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t s
                                                                   L.I, L.O, L.C(), L.grid, ginfo_out, L.nk());
 }
 
+// wp / wt / ginfo: one pointer per layer.  Returns false (nothing launched) when the model has more layers than one
+// launch takes; the caller then packs layer by layer.
+bool launch_pack_model(const LayerView* layers, int n_layers, float* const* wp, float* const* wt, float* const* ginfo,
+                       unsigned* clear, int clear_words, hipStream_t st) {
+  if (n_layers > kPackLayersMax) return false;
+  PackModelArgs args;
+  int blocks = 1;
+  for (int l = 0; l < n_layers; ++l) {
+    const LayerView& L = layers[l];
+    args.layer[l] = PackLayer{L.base_w, L.spline_w, L.scaler, L.grid, wp[l], wt[l], ginfo[l], L.I, L.O, L.C(), L.nk()};
+    const int b = (L.O * L.I * (L.C() + 1) + 255) / 256;
+    if (b > blocks) blocks = b;
+  }
+  for (int l = n_layers; l < kPackLayersMax; ++l) args.layer[l] = args.layer[0];
+  args.clear = clear; args.clear_words = clear_words;
+  if (blocks > 1024) blocks = 1024;
+  pack_model_kernel<<<dim3(blocks, n_layers), 256, 0, st>>>(args);
+  return true;
+}
+
 template <int D, int D2>
 static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, int I, hipStream_t st) {
   const int64_t total = N * I;
@@ -805,6 +922,12 @@ void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, fl
                           float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel) {
   const int edges = L.O * L.I;
   const float* src = part;
+  if ((nchunks > 1 || sel.ginfo) && L.C() + 1 <= 64) {   // both steps in one launch
+    const int EB = 64 / (L.C() + 1);
+    sum_unpack_kernel<<<(unsigned)((edges + EB - 1) / EB), 64 * kSumWaves, 0, st>>>(
+        part, nchunks, sel, L.spline_w, L.scaler, g_base, g_spline, g_scaler, L.I, L.O, L.C(), accumulate);
+    return;
+  }
   if (nchunks > 1 || sel.ginfo) {
     const size_t total = L.packed_floats();
     sum_partials_kernel<<<(unsigned)((total + 63) / 64), 64 * kSumWaves, 0, st>>>(part, nchunks, total, sum_buf, sel);

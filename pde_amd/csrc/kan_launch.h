@@ -42,6 +42,9 @@ void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, b
 // out12[e] <- pass k's (value share, first k, time in pass 0, second k); the value shares are summed over k = 0..4
 void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st, JetSkip skip = {});
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st, float* ginfo_out = nullptr);
+constexpr int kPackLayersMax = 8;
+bool launch_pack_model(const LayerView* layers, int n_layers, float* const* wp, float* const* wt, float* const* ginfo,
+                       unsigned* clear, int clear_words, hipStream_t st);
 bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t stride_d, float* a, int64_t N,
                       int I, hipStream_t st);
 // amax_out: where the per-slot maxima of y (1 + D + D2 words) are combined into, or nullptr

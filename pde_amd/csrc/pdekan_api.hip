@@ -507,10 +507,15 @@ bool carve(const ModelPlan& P, void* ws, size_t ws_bytes, ModelWs& W, size_t* ne
 // Per call: knot-row classes, packed weights and the tables / planes derived from them, for every layer.
 int pack_model(ModelPlan& P, const ModelWs& W, const ModelStats& S, hipStream_t st) {
   const int nl = (int)P.L.size();
-  hipError_t e = hipMemsetAsync(S.base, 0, S.bytes(), st);
-  if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "clearing the scale maxima: %s", hipGetErrorString(e));
+  // one launch: every layer's packed weights and knot-row classes, and the scale maxima cleared
+  const bool packed = pdekan::launch_pack_model(P.L.data(), nl, W.wp.data(), W.wt.data(), W.ginfo.data(), S.base,
+                                                (int)(S.bytes() / 4), st);
+  if (!packed) {
+    hipError_t e = hipMemsetAsync(S.base, 0, S.bytes(), st);
+    if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "clearing the scale maxima: %s", hipGetErrorString(e));
+  }
   for (int l = 0; l < nl; ++l) {
-    pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st, W.ginfo[l]);   // knot-row classes in the same launch
+    if (!packed) pdekan::launch_pack_weights(P.L[l], W.wp[l], W.wt[l], st, W.ginfo[l]);   // (knot-row classes too)
     P.L[l].ginfo = W.ginfo[l];
     if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
     if (W.wpl[l]) {
