@@ -462,6 +462,23 @@ sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, f
   }
 }
 
+// loss = inv_n * sum of the per-block partials: the first 256 threads of a block (every thread of the block must
+// call), always in the same order
+__device__ __forceinline__ void loss_finish_block(float (&s_w)[4], const float* __restrict__ loss_part, int nparts,
+                                                  float inv_n, float* __restrict__ loss_out, int accumulate) {
+  float local = 0.0f;
+  if (threadIdx.x < 256) {
+    for (int t = threadIdx.x; t < nparts; t += 256) local += loss_part[t];
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = local;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
+    *loss_out = accumulate ? (*loss_out + v) : v;
+  }
+}
+
 // --------------------------------------------------------------------------
 // The two kernels below in one launch (C + 1 <= 64): a block takes 64 / (C+1) whole edges, adds their elements over
 // the chunks exactly as sum_partials_kernel does (same order, same result bit for bit) and unpacks them as
@@ -470,9 +487,14 @@ sum_partials_kernel(const float* __restrict__ part, int nchunks, size_t total, f
 __global__ void __launch_bounds__(64 * kSumWaves)
 sum_unpack_kernel(const float* __restrict__ part, int nchunks, ChunkSelect sel, const float* __restrict__ spline_w,
                   const float* __restrict__ scaler, float* __restrict__ g_base, float* __restrict__ g_spline,
-                  float* __restrict__ g_scaler, int I, int O, int C, int accumulate) {
+                  float* __restrict__ g_scaler, int I, int O, int C, int accumulate, LossJob loss) {
   __shared__ float s_r[kSumWaves][64];
   __shared__ float s_sum[64];
+  if (loss.out && blockIdx.x == gridDim.x - 1) {          // one block more than the edges need: the step's loss
+    __shared__ float s_w[4];
+    loss_finish_block(s_w, loss.part, loss.nparts, loss.inv_n, loss.out, loss.accumulate);
+    return;
+  }
   const int C1 = C + 1, EB = 64 / C1, edges = O * I;
   const size_t total = (size_t)edges * C1;
   if (sel.ginfo) {                            // which run of chunks holds this call's partials: settled by the knot rows
@@ -607,15 +629,7 @@ bs_residual_kernel(const float* __restrict__ x, int64_t stride_n, int64_t stride
 __global__ void loss_finish_kernel(const float* __restrict__ loss_part, int nparts, float inv_n,
                                    float* __restrict__ loss_out, int accumulate) {
   __shared__ float s_w[4];
-  float local = 0.0f;
-  for (int t = threadIdx.x; t < nparts; t += blockDim.x) local += loss_part[t];
-  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float v = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
-    *loss_out = accumulate ? (*loss_out + v) : v;
-  }
+  loss_finish_block(s_w, loss_part, nparts, inv_n, loss_out, accumulate);
 }
 
 // --------------------------------------------------------------------------
@@ -918,16 +932,19 @@ bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a
   return true;
 }
 
+// loss (out != nullptr): the loss reduction of launch_loss_finish rides in the same launch where it can
 void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
-                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel) {
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel,
+                          LossJob loss) {
   const int edges = L.O * L.I;
   const float* src = part;
   if ((nchunks > 1 || sel.ginfo) && L.C() + 1 <= 64) {   // both steps in one launch
     const int EB = 64 / (L.C() + 1);
-    sum_unpack_kernel<<<(unsigned)((edges + EB - 1) / EB), 64 * kSumWaves, 0, st>>>(
-        part, nchunks, sel, L.spline_w, L.scaler, g_base, g_spline, g_scaler, L.I, L.O, L.C(), accumulate);
+    sum_unpack_kernel<<<(unsigned)((edges + EB - 1) / EB) + (loss.out ? 1 : 0), 64 * kSumWaves, 0, st>>>(
+        part, nchunks, sel, L.spline_w, L.scaler, g_base, g_spline, g_scaler, L.I, L.O, L.C(), accumulate, loss);
     return;
   }
+  if (loss.out) launch_loss_finish(loss.part, loss.nparts, loss.inv_n, loss.out, loss.accumulate, st);
   if (nchunks > 1 || sel.ginfo) {
     const size_t total = L.packed_floats();
     sum_partials_kernel<<<(unsigned)((total + 63) / 64), 64 * kSumWaves, 0, st>>>(part, nchunks, total, sum_buf, sel);

@@ -28,6 +28,8 @@ struct LayerView {
 // spaced (settled on the device from the layer's ginfo): with ginfo set, the kernel returns at once in that case.
 struct JetSkip { const float* ginfo = nullptr; int I = 0; };
 
+// the loss reduction of a step (launch_loss_finish) as a job another launch can carry
+struct LossJob { const float* part = nullptr; int nparts = 0; float inv_n = 0.f; float* out = nullptr; int accumulate = 0; };
 struct ChunkSelect { const float* ginfo = nullptr; int I = 0, first_uniform = 0, n_uniform = 0, first_other = 0, n_other = 0; };
 
 // kan_kernels.hip
@@ -59,7 +61,8 @@ bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a
 // sel.ginfo given: the chunks summed are [first_uniform, + n_uniform) when every knot row of the layer is (nearly)
 // equally spaced, else [first_other, + n_other) - settled on the device (nchunks is not used then)
 void launch_reduce_unpack(const LayerView& L, const float* part, int nchunks, float* sum_buf, float* g_base,
-                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel = {});
+                          float* g_spline, float* g_scaler, int accumulate, hipStream_t st, ChunkSelect sel = {},
+                          LossJob loss = LossJob());
 bool launch_bs_residual(int D, const float* x, int64_t stride_n, int64_t stride_d, const float* vjet,
                         const float* target, float sigma, float rate, float inv_n, float* res, float* gy,
                         float* loss_part, int nblocks, int64_t N, hipStream_t st);

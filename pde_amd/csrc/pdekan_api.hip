@@ -826,15 +826,18 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
         pdekan::launch_head_bs(P.D, H, W.act[nl - 1], xs, stride_n, stride_d, tgt, W.wp[nl - 1], sigma, rate, inv_n,
                                res, (grads && nl > 1) ? W.g[0] : nullptr, grads ? W.part : nullptr, W.loss_part,
                                nblocks, m, st, head_cot);
-        if (loss_out) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
+        // (with gradients asked for, the loss reduction rides in the launch that reduces the head's gradients)
+        if (loss_out && !grads) pdekan::launch_loss_finish(W.loss_part, nblocks, inv_n, loss_out, first ? 0 : 1, st);
       }
       if (grads) {
         const PdekanLayerGrad& g = grads[nl - 1];
         if (!g.base_weight || !g.spline_weight || (H.scaler && !g.spline_scaler))
           return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
         ProfScope ps(st, "L%d.reduce_unpack", nl - 1);
+        pdekan::LossJob lj;
+        if (loss_out) { lj.part = W.loss_part; lj.nparts = nblocks; lj.inv_n = inv_n; lj.out = loss_out; lj.accumulate = first ? 0 : 1; }
         pdekan::launch_reduce_unpack(H, W.part, nblocks, W.part + (size_t)nblocks * H.packed_floats(), g.base_weight,
-                                     g.spline_weight, H.scaler ? g.spline_scaler : nullptr, acc_flag, st);
+                                     g.spline_weight, H.scaler ? g.spline_scaler : nullptr, acc_flag, st, {}, lj);
       }
       top = nl - 2;
     } else {
