@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256)
 fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                    const float* __restrict__ wt, float* __restrict__ y,
                    int64_t N, int I, int O, int G, int act, int PT, int NIC, int i0, int IB, int accumulate,
-                   int skip_near_uniform, unsigned* __restrict__ amax_out) {
+                   int skip_near_uniform, unsigned* __restrict__ amax_out, SeedSrc seed) {
   constexpr int J = 1 + D + D2;
   if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // a matrix kernel beside this one takes the layer
   const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
@@ -162,10 +162,23 @@ fwd_generic_kernel(const float* __restrict__ a, const float* __restrict__ grid, 
 
   for (int pair = threadIdx.x; pair < npts * IBe; pair += blockDim.x) {
     const int i = pair % IBe, pl = pair / IBe;
-    const float* src = a + ((p0 + pl) * I + i0 + i) * J;
     float jet[J];
+    if (seed.x) {                             // first layer of a model: the jets are built here and left for the backward
+      float* dst = seed.a_out + ((p0 + pl) * I + i0 + i) * J;
+      jet[0] = seed.x[(p0 + pl) * seed.sn + (i0 + i) * seed.sd];
 #pragma unroll
-    for (int j = 0; j < J; ++j) { jet[j] = src[j]; s_jet[pair * J + j] = jet[j]; }
+      for (int d = 0; d < D; ++d) jet[1 + d] = (d == i0 + i) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int d = 0; d < D2; ++d) jet[1 + D + d] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) dst[j] = jet[j];
+    } else {
+      const float* src = a + ((p0 + pl) * I + i0 + i) * J;
+#pragma unroll
+      for (int j = 0; j < J; ++j) jet[j] = src[j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) s_jet[pair * J + j] = jet[j];
     Basis bs;
     eval_basis_row<false>(s_knots + i * (nk + 1), nk, jet[0], bs);
     const Act av = eval_act(act, jet[0]);
@@ -811,13 +824,20 @@ static void seed_t(const float* x, int64_t sn, int64_t sd, float* a, int64_t N, 
 // (the forward launcher narrows it further when a large grid would push a window past 60 KB)
 constexpr int kGenericWindow = 256;
 
-template <int D, int D2>
-static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st, bool skip,
-                  unsigned* amax_out) {
-  constexpr int J = 1 + D + D2;
+// input features per launch of the streaming forward
+template <int J>
+static int fwd_window(const LayerView& L) {
   int IB = L.I < kGenericWindow ? L.I : kGenericWindow;
   const int per_feature = (int)sizeof(EdgeRec) + J * 4 + (L.nk() + 1) * 4;
   if (IB * per_feature > 60 * 1024) IB = (60 * 1024) / per_feature;    // large grids: narrower window
+  return IB;
+}
+
+template <int D, int D2>
+static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y, int64_t N, hipStream_t st, bool skip,
+                  unsigned* amax_out, SeedSrc seed) {
+  constexpr int J = 1 + D + D2;
+  const int IB = fwd_window<J>(L);
   int PT = 256 / IB; if (PT < 1) PT = 1; if (PT > 64) PT = 64;
   int NIC = 1;
   if (PT * L.O < 256) {
@@ -831,7 +851,7 @@ static void fwd_t(const LayerView& L, const float* a, const float* wt, float* y,
   for (int i0 = 0; i0 < L.I; i0 += IB)
     fwd_generic_kernel<D, D2><<<(unsigned)blocks, 256, lds, st>>>(a, L.grid, L.ginfo, wt, y, N, L.I, L.O, L.G, L.act,
                                                                   PT, NIC, i0, IB, i0 > 0, skip ? 1 : 0,
-                                                                  (i0 + IB >= L.I) ? amax_out : nullptr);
+                                                                  (i0 + IB >= L.I) ? amax_out : nullptr, seed);
 }
 
 template <int D, int D2>
@@ -908,12 +928,20 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t sn, int64_t sd, flo
   return true;
 }
 
+// seed (x != nullptr): only for layers fwd_generic_takes_seed() accepts (one window of input features)
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st, bool skip_near_uniform, unsigned* amax_out) {
-#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform, amax_out)
+                        hipStream_t st, bool skip_near_uniform, unsigned* amax_out, SeedSrc seed) {
+#define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform, amax_out, seed)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
   return true;
+}
+
+bool fwd_generic_takes_seed(int D, int D2, const LayerView& L) {
+#define CALL(A, B) return fwd_window<1 + A + B>(L) >= L.I
+  PDEKAN_DISPATCH_JET(D, D2, CALL)
+#undef CALL
+  return false;
 }
 
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, const float* wp,

@@ -28,6 +28,10 @@ struct LayerView {
 // spaced (settled on the device from the layer's ginfo): with ginfo set, the kernel returns at once in that case.
 struct JetSkip { const float* ginfo = nullptr; int I = 0; };
 
+// Seeding of a model's input jets (launch_seed_jets) as a job the first layer's forward can carry: the kernel builds
+// the jets of its inputs from the points x (value, unit first derivative in the feature's own direction) instead of
+// reading them, and leaves them at a_out for the backward pass.
+struct SeedSrc { const float* x = nullptr; int64_t sn = 0, sd = 0; float* a_out = nullptr; };
 // the loss reduction of a step (launch_loss_finish) as a job another launch can carry
 struct LossJob { const float* part = nullptr; int nparts = 0; float inv_n = 0.f; float* out = nullptr; int accumulate = 0; };
 struct ChunkSelect { const float* ginfo = nullptr; int I = 0, first_uniform = 0, n_uniform = 0, first_other = 0, n_other = 0; };
@@ -51,7 +55,11 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t stride_n, int64_t s
                       int I, hipStream_t st);
 // amax_out: where the per-slot maxima of y (1 + D + D2 words) are combined into, or nullptr
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
-                        hipStream_t st, bool skip_near_uniform = false, unsigned* amax_out = nullptr);
+                        hipStream_t st, bool skip_near_uniform = false, unsigned* amax_out = nullptr,
+                        SeedSrc seed = SeedSrc());
+// whether the forward kernels above / below take a SeedSrc for this layer (else the caller seeds first)
+bool fwd_generic_takes_seed(int D, int D2, const LayerView& L);
+bool fwd_sparse_takes_seed(const LayerView& L);
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
                               const float* wp, float* ga, int64_t N, hipStream_t st, bool skip_near_uniform = false);
 int generic_weight_chunks(int64_t N, int I, int O);
@@ -87,7 +95,8 @@ void launch_pack_window(const LayerView& L, const float* wp, float* win, hipStre
 // beside this one does the layer then
 // amax_out: where the per-jet maxima of y are combined into (4 words, see kan_f16.hip), or nullptr
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
-                       bool skip_near_uniform = false, unsigned* amax_out = nullptr);
+                       bool skip_near_uniform = false, unsigned* amax_out = nullptr,
+                       SeedSrc seed = SeedSrc());
 // cot_out: where the per-jet maxima of ga are combined into (4 words), or nullptr
 void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy, const float* win, float* ga,
                              int64_t N, hipStream_t st, bool skip_near_uniform = false, unsigned* cot_out = nullptr);

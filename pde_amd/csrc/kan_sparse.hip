@@ -475,7 +475,8 @@ __device__ __forceinline__ void few_inputs_products(const float* stg, const int*
 __global__ void __launch_bounds__(64 * kFewWaves, 1)
 fwd_sparse_few_inputs_kernel(const float* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
                              const float* __restrict__ win, const float* __restrict__ wbt, float* __restrict__ y, int64_t N,
-                             int I, int G, int act, int OT, int skip_near_uniform, unsigned* __restrict__ amax_out) {
+                             int I, int G, int act, int OT, int skip_near_uniform, unsigned* __restrict__ amax_out,
+                             SeedSrc seed) {
   if (skip_near_uniform && all_rows_near_uniform(ginfo, I)) return;   // the fp16 matrix kernel beside this one takes the layer
   const int o0 = (int)blockIdx.y * 64;
   const int nk = G + 7;
@@ -519,12 +520,19 @@ fwd_sparse_few_inputs_kernel(const float* __restrict__ a, const float* __restric
   // jets of a batch: a wave-uniform row address (the batch's first point, or the last point of all for a batch past
   // the end) plus a 32-bit offset per lane
   f32x4 nxt;
+  // (seed.x given: the jets are built from the points, value + unit derivative in the feature's own direction, and
+  // left at seed.a_out for the backward pass: the first layer of a model)
 #define PDEKAN_FEW_FETCH(B)                                                                          \
   {                                                                                                  \
     const int nl_ = tile_live((B) * kFewBatch, N, kFewBatch);                                        \
-    const float* row_ = a + (nl_ > 0 ? (B) * kFewBatch : N - 1) * I * 4;                             \
+    const int64_t first_ = nl_ > 0 ? (B) * kFewBatch : N - 1;                                        \
     const int r_ = (nl_ > 0 && eval_lane) ? (ept < nl_ ? ept : nl_ - 1) : 0;                         \
-    nxt = *reinterpret_cast<const f32x4*>(row_ + (r_ * I + ef) * 4);                                 \
+    if (seed.x) {                                                                                    \
+      const float v_ = seed.x[(first_ + r_) * seed.sn + ef * seed.sd];                               \
+      nxt = (f32x4){v_, ef == 0 ? 1.0f : 0.0f, ef == 1 ? 1.0f : 0.0f, 0.0f};                         \
+    } else {                                                                                         \
+      nxt = *reinterpret_cast<const f32x4*>(a + first_ * I * 4 + (r_ * I + ef) * 4);                 \
+    }                                                                                                \
   }
   PDEKAN_FEW_FETCH(b)
   for (; b < nbatch; b += bstride) {
@@ -532,6 +540,8 @@ fwd_sparse_few_inputs_kernel(const float* __restrict__ a, const float* __restric
     const int nlive = tile_live(P0, N, kFewBatch);
     const f32x4 cur = nxt;
     PDEKAN_FEW_FETCH(b + bstride)
+    if (seed.x && eval_lane && ept < nlive && blockIdx.y == 0)
+      *reinterpret_cast<f32x4*>(seed.a_out + ((P0 + ept) * I + ef) * 4) = cur;
     if (eval_lane) {
       const Live L = eval_live<false>(sK + ef * kKnotPadS, nk, act, cur[0]);
       const float s2 = cur[1] * cur[1];
@@ -808,7 +818,7 @@ static bool few_inputs_layout(const LayerView& L) {
 }
 
 static void fwd_sparse_few_inputs_launch(const LayerView& L, const float* a, const float* win, float* y, int64_t N,
-                                         hipStream_t st, int skip, unsigned* amax_out) {
+                                         hipStream_t st, int skip, unsigned* amax_out, SeedSrc seed) {
   const float* wbt = win + (size_t)L.I * L.O * 64;
   auto k = fwd_sparse_few_inputs_kernel;
   const size_t lds = ((size_t)kFewInputsMax * 64 * kFewRow + kFewInputsMax * 64 + kFewInputsMax * kKnotPadS +
@@ -820,14 +830,17 @@ static void fwd_sparse_few_inputs_launch(const LayerView& L, const float* a, con
   if (blocks > resident) blocks = resident;
   if (blocks < 1) blocks = 1;
   const dim3 g((unsigned)blocks, L.O / 64);
-  k<<<g, 64 * kFewWaves, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip, amax_out);
+  k<<<g, 64 * kFewWaves, lds, st>>>(a, L.grid, L.ginfo, win, wbt, y, N, L.I, L.G, L.act, L.O, skip, amax_out, seed);
 }
 
+bool fwd_sparse_takes_seed(const LayerView& L) { return few_inputs_layout(L); }
+
+// seed (x != nullptr): only for layers fwd_sparse_takes_seed() accepts
 void launch_fwd_sparse(const LayerView& L, const float* a, const float* win, float* y, int64_t N, hipStream_t st,
-                       bool skip_near_uniform, unsigned* amax_out) {
+                       bool skip_near_uniform, unsigned* amax_out, SeedSrc seed) {
   const int skip = skip_near_uniform ? 1 : 0;
   if (few_inputs_layout(L)) {
-    fwd_sparse_few_inputs_launch(L, a, win, y, N, st, skip, amax_out);
+    fwd_sparse_few_inputs_launch(L, a, win, y, N, st, skip, amax_out, seed);
   } else if (!window_layout(L)) {
     fwd_sparse_launch<64, 4, kRawRow>(L, a, win, y, N, st, skip, amax_out);
   } else if (L.O == 64) {

@@ -165,8 +165,23 @@ struct F16Io {
 
 // act_out (with a layer the sparse kernel takes): where that kernel leaves the per-jet maxima of y for an fp16
 // matrix layer above
+// seed (model-level calls, layer 0): the layer's input jets a are still to be built from the points; the kernels that
+// can do that themselves (and leave the jets at a for the backward pass) save the seeding launch
 int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* wt, const float* win,
-                float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr, unsigned* act_out = nullptr) {
+                float* y, int64_t n, hipStream_t st, int li = 0, const F16Io* h = nullptr, unsigned* act_out = nullptr,
+                const pdekan::SeedSrc* seed = nullptr) {
+  pdekan::SeedSrc fused;                      // what the forward kernel is given (empty: it reads a)
+  if (seed) {
+    const bool f16_route = h && h->wpl;
+    const bool sparse_route = !f16_route && win && pdekan::sparse_eligible(D, D2, L);
+    const bool generic_route = !f16_route && !sparse_route && !pdekan::mfma_eligible(D, D2, L);
+    if ((sparse_route && pdekan::fwd_sparse_takes_seed(L)) || (generic_route && pdekan::fwd_generic_takes_seed(D, D2, L))) {
+      fused = *seed;
+    } else {
+      ProfScope ps(st, "seed_jets", 0);
+      pdekan::launch_seed_jets(D, D2, seed->x, seed->sn, seed->sd, seed->a_out, n, L.I, st);
+    }
+  }
   if (h && h->wpl && D == 6) {
     // 12 jets: the fp16 matrix kernel on whole groups of 8 points when every knot row is (nearly) equally spaced, else
     // the streaming kernel (decided on the device); the last n % 8 points always stream
@@ -192,13 +207,13 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
     pdekan::launch_fwd_sparse(L, a, win, y, n, st, true, h->act_out);
   } else if (win && pdekan::sparse_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.sparse", li);
-    pdekan::launch_fwd_sparse(L, a, win, y, n, st, false, act_out);
+    pdekan::launch_fwd_sparse(L, a, win, y, n, st, false, act_out, fused);
   } else if (pdekan::mfma_eligible(D, D2, L)) {
     ProfScope ps(st, "L%d.fwd.mfma", li);
     pdekan::launch_fwd_mfma(L, a, wt, y, n, st);
   } else {
     ProfScope ps(st, "L%d.fwd.stream", li);
-    if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st, false, act_out))
+    if (!pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n, st, false, act_out, fused))
       return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
   }
   return check_launch("layer forward");
@@ -529,10 +544,15 @@ int pack_model(ModelPlan& P, const ModelWs& W, const ModelStats& S, hipStream_t 
 // Forward of layer l of a model on m points.  have_act: the per-jet maxima of the layer's input are already in
 // S.act(l) (the layer before was an fp16 matrix kernel too and left them there).
 int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& S, int l, float* dst, int64_t m,
-                        hipStream_t st, bool* act_ready) {
+                        hipStream_t st, bool* act_ready, const pdekan::SeedSrc* seed = nullptr) {
   const int nl = (int)P.L.size();
   F16Io io;
   const bool f16 = W.wpl[l] != nullptr;
+  if (seed && f16) {                          // the maxima of the input jets are measured below: they have to exist
+    ProfScope ps(st, "seed_jets", 0);
+    pdekan::launch_seed_jets(P.D, P.D2, seed->x, seed->sn, seed->sd, seed->a_out, m, P.L[l].I, st);
+    seed = nullptr;
+  }
   if (f16) {
     if (!*act_ready) {
       ProfScope ps(st, "L%d.jet_absmax", l);
@@ -548,7 +568,7 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
   // and so can a 12-jet layer on the streaming kernel (the first layer of a 6-input model)
   if (!f16 && P.D == 6 && l + 1 < nl && W.wpl[l + 1]) sparse_out = S.act(l + 1);
   *act_ready = (f16 && io.act_out != nullptr) || sparse_out != nullptr;
-  return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out);
+  return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out, seed);
 }
 
 // Tables of one layer-level call, carved from the caller's workspace in this order.
@@ -755,13 +775,13 @@ int pdekan_model_forward_jet(const PdekanLayer* layers, int32_t n_layers, const 
   const int out_w = P.L[nl - 1].O;
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
     const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
-    pdekan::launch_seed_jets(P.D, P.D2, x + p0 * stride_n, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
+    const pdekan::SeedSrc seed = {x + p0 * stride_n, stride_n, stride_d, W.act[0]};   // layer 0 builds its input jets
     if (p0 > 0 && hipMemsetAsync(S.base, 0, S.per_batch_bytes(), st) != hipSuccess)
       return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
     bool act_ready = false;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out_jet + p0 * out_w * P.J : W.act[l + 1];
-      rc = model_layer_forward(P, W, S, l, dst, m, st, &act_ready);
+      rc = model_layer_forward(P, W, S, l, dst, m, st, &act_ready, l == 0 ? &seed : nullptr);
       if (rc) return rc;
     }
   }
@@ -796,10 +816,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   for (int64_t p0 = 0; p0 < n; p0 += P.mb) {
     const int64_t m = (n - p0 < P.mb) ? (n - p0) : P.mb;
     const float* xs = x + p0 * stride_n;
-    {
-      ProfScope ps(st, "seed_jets", 0);
-      pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
-    }
+    const pdekan::SeedSrc seed = {xs, stride_n, stride_d, W.act[0]};   // layer 0 builds its input jets (or is given them first)
     const pdekan::LayerView& H = P.L[nl - 1];
     const bool fused_head = pdekan::head_eligible(P.D, H) && !getenv_flag("PDEKAN_DISABLE_FUSED_HEAD");
     const int n_fwd = fused_head ? nl - 1 : nl;
@@ -807,8 +824,12 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
       return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
     bool act_ready = false;
     for (int l = 0; l < n_fwd; ++l) {
-      rc = model_layer_forward(P, W, S, l, W.act[l + 1], m, st, &act_ready);
+      rc = model_layer_forward(P, W, S, l, W.act[l + 1], m, st, &act_ready, l == 0 ? &seed : nullptr);
       if (rc) return rc;
+    }
+    if (n_fwd == 0) {                           // a one-layer model on the fused head: nobody else builds its input jets
+      ProfScope ps(st, "seed_jets", 0);
+      pdekan::launch_seed_jets(P.D, P.D2, xs, stride_n, stride_d, W.act[0], m, P.L[0].I, st);
     }
     const float* tgt = target ? target + p0 : nullptr;
     float* res = res_out ? res_out + p0 : nullptr;
