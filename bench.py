@@ -36,6 +36,12 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 # 16-bit MFMA products per fp32-accurate product in the split-operand kernels
 SPLIT_PRODUCTS = {"mfma_bf16x3": 6, "mfma_f16x2": 3}
+# what "dtype": "f32" stands for in the line: inputs, outputs, accumulation and every vector-ALU kernel are fp32; the
+# hidden-layer contractions multiply fp32 operands as two fp16 pieces each (three fp16 matrix products per fp32
+# product, fp32 accumulate): 22 significant bits relative to each tensor's per-jet maximum, not elementwise fp32
+ARITHMETIC = ("fp32 storage and accumulation; hidden-layer products as fp16 two-piece splits (hi*hi + hi*lo + lo*hi "
+              "on the fp16 matrix cores, 22 bits relative to the per-jet maximum of each tensor); first layer, head, "
+              "residual, loss and reductions in fp32 on the vector ALUs / fp32 matrix cores")
 
 WORKLOADS = {
     "cfg1": dict(widths=[2, 5, 1], grid=5, pts_per_gpu=10_000),
@@ -69,6 +75,8 @@ def kernel_cost(name, widths, grid, n_pts, J):
     I, O = widths[layer], widths[layer + 1]
     parts = name.split(".")
     kind, impl = parts[1], (parts[2] if len(parts) > 2 else "")
+    if impl == "standby":                   # launched beside the kernel that does the layer; returns at once on the device
+        return 0.0, 0.0, PEAK_FP32_TFLOPS, 0.0
     dense = 2.0 * J * I * C1 * O * n_pts
     if kind == "fwd":
         byts = 4.0 * J * (I + O) * n_pts
@@ -197,6 +205,30 @@ def cpu_baseline_cfg1(act, steps=5):
     return base
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh children of this script, one rank per GPU (the
+    environment torch.distributed.run would give them), before this process has made any GPU call.  Rank 0 prints the
+    one JSON line on the inherited stdout; the other ranks' stdout goes to stderr.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        if rc != 0 and worst == 0:
+            worst = rc if rc > 0 else 128 - rc
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,18 +248,21 @@ def main():
                     help="skip the short extra run at cfg3's per-GPU point count on the default one-GPU line")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the all-reduce path")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even with --gpus 1 (the path `--gpus N` takes without a launcher)")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))    # plain `python bench.py --gpus N`: one fresh child per GPU, no GPU call here
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or args.force_dist:
+    if world > 1 or args.force_dist or args.spawn:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -369,7 +404,7 @@ def main():
         "metric": "collocation pts/s per KAN-PINN train step",
         "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
         "config": {"workload": f"{name}: KAN {widths} grid={grid} k=3 {'SiLU' if args.base_activation == 'silu' else 'Identity'}, Black-Scholes PINN step "
                                f"(fwd + residual + loss + bwd + AdamW), {n_local} points/GPU, {n_global} total",
                    "points_per_gpu": n_local, "points_total": n_global, "micro_batch": args.micro_batch,

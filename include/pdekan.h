@@ -102,7 +102,8 @@ int pdekan_layer_forward(const PdekanLayer* layer, const float* x_jet, float* y_
  * frees nothing.  A layer whose tables exceed that size is refused with PDEKAN_ERR_WORKSPACE (a 128 -> 128 layer
  * at grid 10 fits; 256 -> 256 at grid 20 does not).  All calls on one GPU share that GPU's array: calls that
  * overlap on one GPU (different streams or threads) race; calls on one stream are ordered.  The first call on
- * a device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+ * a device looks the array's address up (hipGetSymbolAddress): make it outside graph capture.  The scratch used
+ * is that of the CURRENT device (hipGetDevice): `stream` must belong to it, as must every pointer passed. */
 #define PDEKAN_NOALLOC_SCRATCH_BYTES (8u << 20)
 int pdekan_layer_forward_noalloc(const PdekanLayer* layer, const float* x_jet, float* y_jet, int64_t n,
                                  int32_t n_dir, int32_t n_second, void* stream);

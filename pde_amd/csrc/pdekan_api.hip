@@ -18,6 +18,10 @@
 static __device__ __align__(256) unsigned char scratch[PDEKAN_NOALLOC_SCRATCH_BYTES];
 
 namespace pdekan {
+// a refused raise of a kernel's dynamic-LDS limit, kept until the entry point's launch check reports it (the launch
+// that follows would only say "invalid argument")
+thread_local char g_lds_refused[200] = "";
+
 void ensure_dynamic_lds(const void* kernel, size_t bytes) {
   if (bytes <= 48 * 1024) return;
   static std::mutex mu;
@@ -27,7 +31,12 @@ void ensure_dynamic_lds(const void* kernel, size_t bytes) {
   std::lock_guard<std::mutex> lock(mu);
   size_t& g = granted[{dev, kernel}];
   if (g >= bytes) return;
-  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) g = bytes;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) g = bytes;
+  else
+    snprintf(g_lds_refused, sizeof(g_lds_refused),
+             "raising a kernel's dynamic LDS limit to %zu bytes on device %d failed: %s (first launch of a kernel shape "
+             "inside stream capture?)", bytes, dev, hipGetErrorString(e));
 }
 }  // namespace pdekan
 
@@ -45,6 +54,12 @@ int fail(int code, const char* fmt, ...) {
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
+  if (pdekan::g_lds_refused[0]) {
+    const int rc = fail(PDEKAN_ERR_HIP, "%s: %s%s%s", what, pdekan::g_lds_refused, e != hipSuccess ? "; then " : "",
+                        e != hipSuccess ? hipGetErrorString(e) : "");
+    pdekan::g_lds_refused[0] = 0;
+    return rc;
+  }
   if (e != hipSuccess) return fail(PDEKAN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   return PDEKAN_OK;
 }
@@ -192,7 +207,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
         ProfScope ps(st, "L%d.fwd.mfma_f16x2", li);
         pdekan::launch_fwd12_f16(L, a, h->wpl, y, n8, h->act_in, h->wmax, st);
       }
-      ProfScope ps(st, "L%d.fwd.stream", li);
+      ProfScope ps(st, "L%d.fwd.standby", li);        // (returns at once unless a knot row is far from equal spacing)
       pdekan::launch_fwd_generic(D, D2, L, a, wt, y, n8, st, true);
     }
     if (n > n8) {
@@ -372,7 +387,7 @@ int run_backward_jets12(const pdekan::LayerView& L, const float* a, const float*
       ProfScope ps(st, "L%d.bwd_input.mfma_f16x2", li);
       pdekan::launch_bwd_input12_f16(L, a, gy, h->wpl, ga, n16, h->cot_in, h->wmax, st);
     }
-    ProfScope ps(st, view ? "L%d.split_passes" : "L%d.bwd.stream", li);
+    ProfScope ps(st, "L%d.bwd.standby", li);           // (split passes / streaming kernels: return at once as above)
     if (!view) {
       if (g) pdekan::launch_bwd_weight_generic(6, 5, L, a, gy, part_split, jets12_other_chunks(L, n16, nch, false), n16, st, true);
       if (ga) pdekan::launch_bwd_input_generic(6, 5, L, a, gy, wp, ga, n16, st, true);

@@ -31,9 +31,14 @@ def shard_points(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 def sync_replicas(tensors, dist_module, check_only: bool = False) -> None:
     """Make the replicated tensors of every rank equal to rank 0's (one broadcast of one flat message), or, with
-    ``check_only``, compare them with rank 0's and raise ``RuntimeError`` on the ranks that differ."""
-    tensors = [t.detach() for t in tensors]
-    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    ``check_only``, compare them with rank 0's and raise ``RuntimeError`` on the ranks that differ.
+
+    The message is the tensors' BYTES (uint8 views, whatever their dtypes): float64 parameters and integer buffers
+    travel unrounded, and the comparison is of bit patterns, so a NaN that every rank holds is not a mismatch."""
+    tensors = [t.detach() for t in tensors if t.numel() > 0]
+    if not tensors:
+        return
+    flat = torch.cat([t.contiguous().reshape(-1).view(torch.uint8) for t in tensors])
     ref = flat.clone()
     dist_module.broadcast(ref, src=0)
     if check_only:
@@ -45,10 +50,13 @@ def sync_replicas(tensors, dist_module, check_only: bool = False) -> None:
             raise RuntimeError(f"pde_amd.dist: replicated tensors differ from rank 0's on {int(bad.item())} rank(s); "
                                "seed or load every rank identically, or pass sync='broadcast'")
         return
+    if dist_module.get_rank() == 0:                # rank 0 holds the source: nothing to copy back
+        return
     off = 0
     for t in tensors:
-        t.copy_(ref[off: off + t.numel()].view_as(t).to(t.dtype))
-        off += t.numel()
+        nbytes = t.numel() * t.element_size()
+        t.copy_(ref[off: off + nbytes].clone().view(t.dtype).view_as(t))    # (clone: a view needs an aligned offset)
+        off += nbytes
 
 
 class FlatAllReduce:

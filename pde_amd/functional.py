@@ -69,8 +69,24 @@ def seed_jets(x: torch.Tensor, n_dir: int, n_second: int) -> torch.Tensor:
     return jet
 
 
+def _dense_layer(x, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size, spline_order):
+    """``KANLinear.forward`` (kan.py:153-166) of ``x [N, in]`` as its defining expression around the dense-basis
+    kernel: every op in it is differentiable to any order (``_BasisDense`` carries its own derivative rule)."""
+    bases = _BasisDense.apply(x, grid, 0, grid_size, spline_order)
+    act = torch.nn.functional.silu(x) if act_kind == ACT_SILU else x
+    w = spline_weight if spline_scaler is None else spline_weight * spline_scaler.unsqueeze(-1)
+    return torch.nn.functional.linear(act, base_weight) + \
+        torch.nn.functional.linear(bases.reshape(x.size(0), -1), w.reshape(w.size(0), -1))
+
+
 class _KanLayerJet(torch.autograd.Function):
-    """y_jet = layer(x_jet); backward gives gx_jet and the parameter gradients."""
+    """y_jet = layer(x_jet); backward gives gx_jet and the parameter gradients.
+
+    First-order backward (``loss.backward()``, run1.py:225) is the library's backward kernels.  A backward that is
+    itself being recorded (``torch.autograd.grad(..., create_graph=True)``, the nested-gradient way of forming
+    the s_x / s_xx of run1.py:122-123) cannot come from an opaque kernel call: for plain values (J = 1) it is then
+    formed by differentiating the layer's defining expression around the dense-basis kernel, which is closed under
+    differentiation of any order; for jets (J > 1) it raises - ``forward_jet`` already carries those derivatives."""
 
     @staticmethod
     def forward(ctx, x_jet, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size,
@@ -87,17 +103,23 @@ class _KanLayerJet(torch.autograd.Function):
             ws = _workspace(lib.pdekan_layer_workspace_bytes(ctypes.byref(layer), n, n_dir, n_second), xj.device)
             _lib.check(lib.pdekan_layer_forward(ctypes.byref(layer), _ptr(xj), _ptr(y), n, n_dir, n_second,
                                                 _ptr(ws), ws.numel(), _stream(xj.device)))
-        ctx.save_for_backward(xj, g, bw, sw, sc if sc is not None else torch.empty(0))
-        ctx.meta = (act_kind, grid_size, spline_order, n_dir, n_second, sc is not None)
+        # the inputs themselves (not detached copies): a recorded backward differentiates through them
+        ctx.save_for_backward(x_jet, grid, base_weight, spline_weight,
+                              spline_scaler if spline_scaler is not None else torch.empty(0))
+        ctx.meta = (act_kind, grid_size, spline_order, n_dir, n_second, spline_scaler is not None)
         return y
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        lib = _lib.load()
-        xj, g, bw, sw, sc = ctx.saved_tensors
+        x_jet, grid, base_weight, spline_weight, spline_scaler = ctx.saved_tensors
         act_kind, grid_size, spline_order, n_dir, n_second, has_sc = ctx.meta
-        sc = sc if has_sc else None
+        spline_scaler = spline_scaler if has_sc else None
+        if torch.is_grad_enabled():                    # this backward is being recorded (create_graph=True)
+            return _KanLayerJet._recorded_backward(ctx, gy, x_jet, grid, base_weight, spline_weight, spline_scaler)
+        lib = _lib.load()
+        xj = _prep(x_jet, "input")
+        g, bw, sw = _prep(grid, "grid"), _prep(base_weight, "base_weight"), _prep(spline_weight, "spline_weight")
+        sc = _prep(spline_scaler, "spline_scaler")
         gy = _prep(gy, "grad_output")
         n = xj.shape[0]
         layer = layer_struct(g, bw, sw, sc, act_kind, grid_size, spline_order)
@@ -115,6 +137,25 @@ class _KanLayerJet(torch.autograd.Function):
                                                  _ptr(gx), ctypes.byref(grads) if need_w else None, 0,
                                                  _ptr(ws), ws.numel(), _stream(xj.device)))
         return gx, None, gbw, gsw, gsc, None, None, None, None, None
+
+    @staticmethod
+    def _recorded_backward(ctx, gy, x_jet, grid, base_weight, spline_weight, spline_scaler):
+        act_kind, grid_size, spline_order, n_dir, n_second, _ = ctx.meta
+        if n_dir or n_second:
+            raise RuntimeError(
+                "pde_amd: a differentiable backward (create_graph=True) through a layer on jets is not provided; "
+                "KAN.forward_jet already returns the input derivatives that nested gradients would form, and its "
+                "first-order backward gives their parameter gradients")
+        with torch.enable_grad():
+            y = _dense_layer(x_jet.squeeze(-1), grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size,
+                             spline_order).unsqueeze(-1)
+            wanted = [(i, t) for i, t in ((0, x_jet), (2, base_weight), (3, spline_weight), (4, spline_scaler))
+                      if t is not None and ctx.needs_input_grad[i]]
+            got = torch.autograd.grad(y, [t for _, t in wanted], gy, create_graph=True, allow_unused=True)
+        out = [None] * 10
+        for (i, _), g in zip(wanted, got):
+            out[i] = g
+        return tuple(out)
 
 
 def kan_layer_jet(x_jet, grid, base_weight, spline_weight, spline_scaler, act_kind, grid_size, spline_order,

@@ -123,10 +123,10 @@ class KANLinear(torch.nn.Module):
             # cannot see inside a whole-layer library call.  Under them the layer is its defining expression
             # (kan.py:153-166): two GEMMs around the dense bases.  On a GPU the bases come from the library's
             # basis kernel, an elementwise op that carries its own derivative, vmap and forward-mode rules
-            # (functional.basis_dense), so jacrev / hessian of any depth stay on it; on a CPU tensor (no kernels
-            # there) they are plain tensor code.  O(n^2)/O(n^3) like the scripts either way; forward_jet gives the
+            # (functional.basis_dense), so jacrev / hessian of any depth stay on it; on a CPU tensor or in another
+            # dtype than float32 (no kernels there) they are plain tensor code.  O(n^2)/O(n^3) like the scripts either way; forward_jet gives the
             # same derivatives in O(n).
-            if grid.is_cuda and 0 <= self.spline_order <= 5:
+            if flat.is_cuda and grid.is_cuda and flat.dtype == torch.float32 and 0 <= self.spline_order <= 5:
                 bases = K.basis_dense(flat, grid, self.grid_size, self.spline_order)
             else:
                 bases = dense_bsplines(flat, grid, self.spline_order)

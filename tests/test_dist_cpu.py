@@ -76,7 +76,12 @@ def _worker_mismatched(rank, world, port, n_total, q):
         DataParallelStep(step, dist, params=_layer_tensors(layers), sync="check")
     except RuntimeError:
         raised = True
-    dp = DataParallelStep(step, dist, params=_layer_tensors(layers), sync="broadcast")
+    # other dtypes travel as bytes: a float64 that float32 cannot hold, an integer above 2^24, a NaN every rank shares
+    extras = [torch.tensor([1.0 + 1e-12 * (rank + 1)], dtype=torch.float64),
+              torch.tensor([(1 << 24) + 1 + 2 * rank], dtype=torch.int64), torch.tensor([float("nan")])]
+    dp = DataParallelStep(step, dist, params=_layer_tensors(layers) + extras, sync="broadcast")
+    assert extras[0].item() == 1.0 + 1e-12 and extras[1].item() == (1 << 24) + 1
+    DataParallelStep(step, dist, params=_layer_tensors(layers) + extras, sync="check")   # identical now, NaN included
     x = torch.rand(n_total, 2, generator=torch.Generator().manual_seed(4))
     loss = dp(shard_points(x, rank, world), n_global=n_total)
     q.put((rank, raised, float(loss), dp.step.flat_grad.clone()))

@@ -393,7 +393,7 @@ def test_split_bf16_weight_gradients_match_oracle(widths, N, act, monkeypatch):
                                               ([6, 128, 128, 1], 10, 1 << 17, 1 << 12)])
 def test_large_batch_gradients_match_fp64_oracle(widths, G, N, shard):
     """The benchmark configuration at its full size (2^20 points), the wide grid-20 model and the 5-asset basket
-    model (12 jets per value, streaming kernels) at 2^17: loss and every
+    model (12 jets per value: 12-jet fp16 matrix kernels for the hidden layer, streaming first layer) at 2^17: loss and every
     parameter gradient of the fused step against the fp64 oracle, which is evaluated here on the GPU shard by shard
     (the loss is a sum over points, pinn_step's n_global).  Long sums are where accumulation order and rounding
     show: the matrix instructions' accumulate drifts with the length of a run of steps, which the weight-gradient
@@ -424,6 +424,60 @@ def test_large_batch_gradients_match_fp64_oracle(widths, G, N, shard):
             err = max_rel(step.flat_grad[off:off + n].double(), flat64[off:off + n])
             assert err <= TOL, (l, k, err)
             off += n
+
+
+@pytest.mark.parametrize("widths,G", [([2, 256, 256, 256, 1], 20), ([6, 128, 128, 1], 10)])
+def test_wide_models_at_their_full_point_count(widths, G):
+    """The wide grid-20 model and the 5-asset basket model at the full 2^22 points of their benchmark
+    configurations, through properties that do not need an oracle of that size:
+      - additivity: the step on all 2^22 points (micro-batches of 2^20) equals the sum of 32 steps on shards of 2^17
+        points with n_global = 2^22, loss and every gradient tensor;
+      - a permutation of the points changes nothing beyond fp32 reassociation;
+      - the first shard's share (n_global = 2^22) against the fp64 oracle.
+    Long runs of matrix-instruction accumulates and many partial chunks are what only this size exercises."""
+    from pde_amd.pinn import BlackScholesStep
+    N, S, shard64 = 1 << 22, 1 << 17, 1 << 12
+    keys = ("base_weight", "spline_weight", "spline_scaler")
+    m = _random_model(widths, G, 91)
+    x = _points_clear_of_knots(m, N, "silu", 4321, device="cuda").cuda()
+    layers64 = [{k: (v.double().cuda() if v is not None else None) for k, v in lay.items()}
+                for lay in O.layers_from_state_dict(m.state_dict())]
+    loss64, flat64 = 0.0, None
+    for s0 in range(0, S, shard64):
+        r = O.pinn_step(x[s0:s0 + shard64].double(), layers64, "silu", n_global=N)
+        loss64 += r["loss"].item()
+        flat = torch.cat([r["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in keys])
+        flat64 = flat if flat64 is None else flat64 + flat
+        del r
+    mg = m.cuda()
+    bounds, off = [], 0
+    for l, lay in enumerate(mg.layers):
+        for k in keys:
+            bounds.append((l, k, off, off + getattr(lay, k).numel()))
+            off += getattr(lay, k).numel()
+
+    def agree(a, b, what):
+        for l, k, lo, hi in bounds:
+            err = max_rel(a[lo:hi].double(), b[lo:hi].double())
+            assert err <= TOL, (what, l, k, err)
+
+    full = BlackScholesStep(mg, micro_batch=1 << 20)
+    l_all = full(x).item()
+    g_all = full.flat_grad.clone()
+    part = BlackScholesStep(mg)
+    l_sum, g_sum = 0.0, torch.zeros_like(g_all, dtype=torch.float64)
+    for s0 in range(0, N, S):
+        l_sum += part(x[s0:s0 + S], n_global=N).item()
+        g_sum += part.flat_grad.double()
+        if s0 == 0:
+            assert abs(l_sum - loss64) <= TOL * abs(loss64)
+            agree(part.flat_grad, flat64, "first shard against the fp64 oracle")
+    assert abs(l_all - l_sum) <= TOL * abs(l_all)
+    agree(g_all, g_sum, "all points against the sum of the shards")
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).cuda()
+    l_perm = full(x[perm]).item()
+    assert abs(l_perm - l_all) <= TOL * abs(l_all)
+    agree(full.flat_grad, g_all, "permuted points")
 
 
 @pytest.mark.parametrize("sparse", ["1", "0"])

@@ -19,35 +19,81 @@ def _flat(grads):
     return torch.cat([g[k].flatten() for g in grads for k in KEYS if g[k] is not None])
 
 
-@pytest.mark.parametrize("widths,G,N", [([2, 64, 64, 1], 10, 1 << 20), ([2, 64, 64, 1], 10, 70000), ([2, 8, 1], 5, 300)])
-def test_step_stays_inside_the_workspace_it_asked_for(widths, G, N):
+@pytest.mark.parametrize("widths,G,N,mb", [([2, 64, 64, 1], 10, 1 << 20, 0), ([2, 64, 64, 1], 10, 70000, 0),
+                                           ([2, 8, 1], 5, 300, 0), ([6, 128, 128, 1], 10, 4107, 0),
+                                           ([6, 128, 128, 1], 10, 4107, 1000), ([2, 64, 64, 1], 10, 70001, 4096)])
+def test_step_stays_inside_the_workspace_it_asked_for(widths, G, N, mb):
     """The step is given exactly the bytes pdekan_model_workspace_bytes() names, inside a larger allocation
     whose remainder holds a pattern: every kernel of the step (the fused head writes one loss partial per
-    block, up to 1280 blocks at this size) must leave that remainder alone, and the result must equal the
-    ordinary call's."""
+    block, up to 1280 blocks at this size; the 12-jet layers lay out matrix chunks, a tail chunk, the chunks of
+    whatever runs instead of the matrix kernels, three 4-jet views and 12-word maxima) must leave that remainder
+    alone, and the result must equal the ordinary call's.  N % 16 != 0 and micro-batches exercise the tails."""
     from pde_amd import _lib, functional as K
     from pde_amd.pinn import BlackScholesStep
     lib = _lib.load()
+    d = widths[0]
     m = _random_model(widths, G, 5).cuda()
-    x = torch.rand(N, 2, generator=torch.Generator().manual_seed(6)).cuda()
-    step = BlackScholesStep(m)
+    x = torch.rand(N, d, generator=torch.Generator().manual_seed(6)).cuda()
+    step = BlackScholesStep(m, micro_batch=mb)
     step(x)
     loss0, grad0 = step.loss.clone(), step.flat_grad.clone()
     layers, grads, nl = step._structs()
-    need = lib.pdekan_model_workspace_bytes(layers, nl, N, 2, 1, 0)
+    need = lib.pdekan_model_workspace_bytes(layers, nl, N, d, d - 1, mb)
     guard = 1 << 16
     buf = torch.empty(need + guard, dtype=torch.uint8, device="cuda")
     buf[need:] = 0xA5
     step.flat_grad.zero_()
     _lib.check(lib.pdekan_bs_step(layers, nl, K._ptr(x), x.stride(0), x.stride(1), None, N, N, step.sigma, step.rate,
-                                  K._ptr(step.loss), None, grads, 0, 0, K._ptr(buf), need, K._stream(x.device)))
+                                  K._ptr(step.loss), None, grads, 0, mb, K._ptr(buf), need, K._stream(x.device)))
     torch.cuda.synchronize()
     assert bool((buf[need:] == 0xA5).all()), "a kernel wrote past the end of the workspace"
     assert torch.equal(step.loss, loss0) and torch.equal(step.flat_grad, grad0)
     # one byte less is refused, not overrun
     rc = lib.pdekan_bs_step(layers, nl, K._ptr(x), x.stride(0), x.stride(1), None, N, N, step.sigma, step.rate,
-                            K._ptr(step.loss), None, grads, 0, 0, K._ptr(buf), need - 257, K._stream(x.device))
+                            K._ptr(step.loss), None, grads, 0, mb, K._ptr(buf), need - 257, K._stream(x.device))
     assert rc == -2
+
+
+@pytest.mark.parametrize("moved", [0.0, 0.015, 0.08])
+@pytest.mark.parametrize("I,O_,N", [(128, 128, 1003), (32, 64, 40)])
+def test_layer_backward_with_12_jets_stays_inside_its_workspace(I, O_, N, moved):
+    """pdekan_layer_backward with (n_dir, n_second) = (6, 5), given exactly pdekan_layer_workspace_bytes(): matrix
+    chunks, the tail chunk and the streaming kernels' chunks share the partial-sum area; equally spaced knot rows
+    (moved = 0) or nearly so (0.015 of a spacing of 0.2) take the 12-jet matrix kernels, rows moved further (0.08) the
+    streaming kernels launched beside them.  The bytes behind the
+    workspace must survive and both runs must agree with a call on an oversized workspace."""
+    from pde_amd import _lib, functional as K
+    from pde_amd._lib import PdekanLayerGrad
+    from pde_amd.kan import KANLinear
+    lib = _lib.load()
+    torch.manual_seed(I + O_)
+    lay = KANLinear(I, O_, grid_size=10).cuda()
+    if moved:
+        with torch.no_grad():
+            lay.grid[:, 3:-3] += 2 * moved * torch.rand(I, 11, device="cuda") - moved
+    gen = torch.Generator().manual_seed(N)
+    xj = (torch.rand(N, I, 12, generator=gen) * 2 - 1).cuda()
+    gy = torch.randn(N, O_, 12, generator=gen).cuda()
+    L = K.layer_struct(lay.grid, lay.base_weight.detach(), lay.spline_weight.detach(), lay.spline_scaler.detach(), 1, 10, 3)
+    need = lib.pdekan_layer_workspace_bytes(ctypes.byref(L), N, 6, 5)
+    guard = 1 << 16
+
+    def run(nbytes_given, total):
+        buf = torch.empty(total, dtype=torch.uint8, device="cuda")
+        buf[nbytes_given:] = 0xA5
+        gx = torch.empty_like(xj)
+        g = [torch.empty_like(lay.base_weight), torch.empty_like(lay.spline_weight), torch.empty_like(lay.spline_scaler)]
+        G = PdekanLayerGrad(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr())
+        _lib.check(lib.pdekan_layer_backward(ctypes.byref(L), K._ptr(xj), K._ptr(gy), N, 6, 5, K._ptr(gx),
+                                             ctypes.byref(G), 0, K._ptr(buf), nbytes_given, K._stream(xj.device)))
+        torch.cuda.synchronize()
+        assert bool((buf[nbytes_given:] == 0xA5).all()), "a kernel wrote past the end of the workspace"
+        return [gx] + g
+
+    exact = run(need, need + guard)
+    roomy = run(4 * need, 4 * need + guard)
+    for a, b in zip(exact, roomy):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("widths,G", [([2, 256, 1], 64), ([2, 256, 1], 48), ([2, 200, 1], 40)])
@@ -225,6 +271,57 @@ def test_jacrev_hessian_callers_stay_on_the_kernels_and_train(golden, monkeypatc
     xs = torch.rand(300, lay.in_features, generator=torch.Generator().manual_seed(1)) * 3.4 - 1.7
     from pde_amd.spline_host import dense_bsplines
     assert max_rel(lay.b_splines(xs.cuda()).cpu(), dense_bsplines(xs, lay.grid.cpu(), 3)) <= 2e-6
+
+
+def test_nested_autograd_grad_through_forward(golden):
+    """The other way of forming run1.py:122-123's derivatives: nested torch.autograd.grad(create_graph=True) through
+    `forward` (the formulation the fixtures themselves were made with on the reference KAN).  The first-order
+    backward of the layer op is then recorded, so it is formed from the dense-basis kernel; values, s_x, s_t, s_xx and
+    the parameter gradients of the residual loss must match the fixture / the fused step."""
+    from pde_amd.pinn import BS_RATE, BS_SIGMA, BlackScholesStep
+    from test_gpu_parity import build_model
+    rec = golden("jacrev_hessian")
+    m = build_model(rec)
+    xt = torch.from_numpy(rec["x"].copy()).cuda().requires_grad_(True)
+    s = m(xt)[:, 0]
+    (g1,) = torch.autograd.grad(s.sum(), xt, create_graph=True)
+    (g2,) = torch.autograd.grad(g1[:, 0].sum(), xt, create_graph=True)
+    s_x, s_t, s_xx = g1[:, 0], g1[:, 1], g2[:, 0]
+    for val, key in ((s, "s"), (s_x, "s_x"), (s_xx, "s_xx"), (s_t, "s_t")):
+        assert max_rel(val.detach().cpu(), rec[key]) <= TOL, key
+    x = xt[:, 0]
+    res = s_t - 0.5 * BS_SIGMA ** 2 * x ** 2 * s_xx - BS_RATE * x * s_x + BS_RATE * s
+    loss = torch.mean(res ** 2)
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    got = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    step = BlackScholesStep(m)
+    loss_fused = step(xt.detach())
+    assert abs(loss.item() - loss_fused.item()) <= TOL * abs(loss_fused.item())
+    assert max_rel(got.cpu(), step.flat_grad.cpu()) <= TOL
+    # jets refuse a recorded backward with a pointer to forward_jet instead of returning constants
+    jet = m.forward_jet(xt.detach())
+    with pytest.raises(RuntimeError, match="forward_jet"):
+        torch.autograd.grad(jet.sum(), list(m.parameters()), create_graph=True)
+
+
+def test_float64_model_on_the_gpu_under_jacrev_takes_the_tensor_code(golden):
+    """The kernels are float32: a float64 model on the GPU under a torch.func transform must compute through the
+    tensor-code bases (as it would on the CPU) instead of raising."""
+    from torch.func import jacrev
+    from test_gpu_parity import build_model
+    rec = golden("jacrev_hessian")
+    m = build_model(rec).double()
+    x = torch.from_numpy(rec["x"][:, 0].copy()).cuda().double()
+    t = torch.from_numpy(rec["x"][:, 1].copy()).cuda().double()
+
+    def net(xx, tt):
+        return m(torch.stack([xx.reshape(-1), tt.reshape(-1)]).permute(1, 0))[:, 0]
+
+    s_x = jacrev(net, argnums=0)(x, t).sum(dim=0)
+    assert s_x.dtype == torch.float64
+    assert max_rel(s_x.cpu(), rec["s_x"]) <= TOL
 
 
 def test_workspace_budget_picks_a_micro_batch_that_fits():
