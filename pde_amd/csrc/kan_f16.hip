@@ -1096,6 +1096,374 @@ bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy,
 }
 
 // ==========================================================================================================
+// weight gradients on 32 x 32 tiles (v_mfma_f32_32x32x16_f16): grid-10 layers whose inputs come in multiples of 64.
+// A matrix instruction of this shape holds the vector issue port for 8 of its 32 cycles (the 16 x 16 x 32 one for 8
+// of its 16), so the same vector work per flop leaves the matrix pipe half as many issue slots short.
+//   wave  = 16 features x C1 columns (224 = 7 row tiles of 32) x 64 outputs (2 column tiles): 14 accumulator tiles
+//           of 16 registers; block = 4 waves = 64 features; one chunk of points per block
+//   step  = 4 points: K = (point, jet) = 16.  Lane (p = lane & 3, f = lane >> 2) expands its (point, feature) pair,
+//           cuts the 20 scaled jets and parks them in the wave's E tile of the NEXT step (two tiles, used in turn:
+//           the park needs no ordering against this step's operand reads); only the 4 columns written two steps
+//           earlier are cleared.  Tile image: [2 planes][2 point pairs][224 columns][2 points x 4 jets x fp16 = 16
+//           bytes], so lane (r = lane & 31, h = lane >> 5) reads its A operand (column 32t + r, points 2h, 2h + 1)
+//           as one 16-byte word out of a contiguous run: no bank conflicts, no padding.
+//   B     = gY rows of the step's points, outputs 32n + r, from global straight into registers two steps ahead,
+//           cut into planes one step ahead.
+// No second register set for long sums here (the accumulators take 224 registers): a chunk is at most about 512
+// points = 384 chained matrix instructions per accumulator, and the chunks are added in fp32 by the reduction.
+// A wave runs in the variant that matches the knot rows of its group of 32 features (the unit in which
+// bwd_weight_mfma_kernel, launched beside with skip_uniform = 1, leaves blocks out).  Output: part[chunk][O][I][C1].
+// ==========================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GyTiles32 { u32x4 h[2], l[2]; };      // 2 output tiles x (2 points x 4 jets)
+
+// E tile of a wave: [2 planes][2 point pairs][FE features][20 rows][2 points x 4 jets x fp16 = 16 bytes].  The rows of
+// a feature: 3 that take what would be columns -3 .. -1, the 13 spline columns, 3 that take columns 13 .. 15, the
+// base-activation column - so a pair's 4 live columns go to 4 consecutive rows whatever its interval, with no
+// range checks, and the rows in between are never read.
+template <int C1>
+struct WgW {
+  static constexpr int FE = 16, COLS = FE * C1, NT = COLS / 32, nk = C1 + 3;
+  static constexpr int FROWS = C1 + 6;                     // rows per feature
+  static constexpr int HALF = FE * FROWS * 4;              // words: one pair of points of every row
+  static constexpr int PLANE = 2 * HALF;
+  static constexpr int TILE = 2 * PLANE;
+  static_assert(COLS % 32 == 0, "whole row tiles of 32 columns");
+  static constexpr int wave_words(bool gen) { return TILE + FE * (gen ? kKnotPadN : kKnotPadU); }
+  // row of expanded column col = f * C1 + c of the wave (c = C1 - 1: base column)
+  static __host__ __device__ constexpr int row_of(int col) {
+    return (col / C1) * FROWS + ((col % C1) < C1 - 1 ? 3 + (col % C1) : FROWS - 1);
+  }
+};
+
+// clear the rows a pair wrote one step earlier (at prev), write the 4 live columns c0 .. c0+3 and the base column
+template <int C1>
+__device__ __forceinline__ void park_wgw(unsigned* feat, unsigned*& prev, const Planes16 (&pp)[5], int c0) {
+  constexpr int PL = WgW<C1>::PLANE;
+  const u32x2 zero = {0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    *reinterpret_cast<u32x2*>(prev + m * 4) = zero;
+    *reinterpret_cast<u32x2*>(prev + m * 4 + PL) = zero;
+  }
+  unsigned* dst = feat + (c0 + 3) * 4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    *reinterpret_cast<u32x2*>(dst + m * 4) = pp[m].h;
+    *reinterpret_cast<u32x2*>(dst + m * 4 + PL) = pp[m].l;
+  }
+  *reinterpret_cast<u32x2*>(feat + (WgW<C1>::FROWS - 1) * 4) = pp[4].h;
+  *reinterpret_cast<u32x2*>(feat + (WgW<C1>::FROWS - 1) * 4 + PL) = pp[4].l;
+  prev = dst;
+}
+
+template <int C1>
+__device__ __forceinline__ TileOps16 read_wgw_tile(const unsigned* sE, int off) {
+  TileOps16 o;
+  o.h = *reinterpret_cast<const u32x4*>(sE + off);
+  o.l = *reinterpret_cast<const u32x4*>(sE + off + WgW<C1>::PLANE);
+  return o;
+}
+
+__device__ __forceinline__ void split_gy_tile32(const f32x4 (&g)[2], const f32x4& t, GyTiles32& G, int n) {
+  const Planes16 p0 = split_jet16(g[0] * t), p1 = split_jet16(g[1] * t);
+  G.h[n] = (u32x4){p0.h.x, p0.h.y, p1.h.x, p1.h.y};
+  G.l[n] = (u32x4){p0.l.x, p0.l.y, p1.l.x, p1.l.y};
+}
+
+__device__ __forceinline__ void mfma_wgw_tile(f32x16 (&acc)[2], const TileOps16& e, const GyTiles32& G) {
+  const f16x8 eh = __builtin_bit_cast(f16x8, e.h), el = __builtin_bit_cast(f16x8, e.l);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(el, __builtin_bit_cast(f16x8, G.h[n]), acc[n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, __builtin_bit_cast(f16x8, G.l[n]), acc[n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, __builtin_bit_cast(f16x8, G.h[n]), acc[n], 0, 0, 0);
+}
+
+// The knot reads of a pair's basis evaluation, issued ahead of the arithmetic (a step early: on one wave per SIMD an
+// LDS read the next instruction depends on is a wait nothing hides).  Same interval guess and the same formulas as
+// eval_basis_uniform_by_quotient / eval_basis_near_uniform.
+template <bool GEN> struct KnotPre;
+template <> struct KnotPre<false> { int s; float k[1]; };
+template <> struct KnotPre<true> { int s; float k[8]; };
+
+template <bool GEN>
+__device__ __forceinline__ KnotPre<GEN> fetch_knots(const float* knots, int nk, const FeatGrid& fg, float x) {
+  KnotPre<GEN> r;
+  const float u = (x - fg.g0) * fg.inv_h;
+  r.s = (u > 0.0f) ? (int)fminf(u, (float)(nk - 2)) : 0;
+  if constexpr (GEN) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.k[i] = knots[r.s - 3 + i];
+  } else {
+    r.k[0] = knots[r.s];
+  }
+  return r;
+}
+
+template <bool GEN>
+__device__ __forceinline__ void basis_from_knots(const KnotPre<GEN>& kp, int nk, const FeatGrid& fg, float x, Basis& out) {
+  out.inside = (int)(x >= fg.g0) & (int)(x < fg.glast);
+  if constexpr (!GEN) {
+    out.c0 = kp.s - kOrder;
+    const float t = out.inside ? (x - kp.k[0]) * fg.inv_h : 0.0f;
+    uniform_cubic_pieces<false>(t, out.inside, fg.inv_h, out);
+  } else {
+    const float a0 = kp.k[0], a1 = kp.k[1], a2 = kp.k[2], a3 = kp.k[3], a4 = kp.k[4], a5 = kp.k[5], a6 = kp.k[6], a7 = kp.k[7];
+    const bool down = (kp.s > 0) & (x < a3), up = (kp.s < nk - 2) & (x >= a4);
+    const float km2 = down ? a0 : (up ? a2 : a1);
+    const float km1 = down ? a1 : (up ? a3 : a2);
+    const float k0 = down ? a2 : (up ? a4 : a3);
+    const float k1 = down ? a3 : (up ? a5 : a4);
+    const float k2 = down ? a4 : (up ? a6 : a5);
+    const float k3 = down ? a5 : (up ? a7 : a6);
+    out.c0 = kp.s + (int)up - (int)down - kOrder;
+    const float r1 = kan_rcp(k1 - k0);
+    const float r2a = kan_rcp(k1 - km1), r2b = kan_rcp(k2 - k0);
+    const float r3a = kan_rcp(k1 - km2), r3b = kan_rcp(k2 - km1), r3c = kan_rcp(k3 - k0);
+    const float b1a = (k1 - x) * r1, b1b = (x - k0) * r1;
+    const float u_a = b1a * r2a, u_b = b1b * r2b;
+    const float b2a = (k1 - x) * u_a, b2b = (x - km1) * u_a + (k2 - x) * u_b, b2c = (x - k0) * u_b;
+    const float q_a = b2a * r3a, q_b = b2b * r3b, q_c = b2c * r3c;
+    const float w_a = -2.0f * u_a * r3a, w_b = 2.0f * (u_a - u_b) * r3b, w_c = 2.0f * u_b * r3c;
+    const bool in = out.inside != 0;
+    out.b[0] = in ? (k1 - x) * q_a : 0.0f;
+    out.b[1] = in ? (x - km2) * q_a + (k2 - x) * q_b : 0.0f;
+    out.b[2] = in ? (x - km1) * q_b + (k3 - x) * q_c : 0.0f;
+    out.b[3] = in ? (x - k0) * q_c : 0.0f;
+    out.d1[0] = in ? -3.0f * q_a : 0.0f;
+    out.d1[1] = in ? 3.0f * (q_a - q_b) : 0.0f;
+    out.d1[2] = in ? 3.0f * (q_b - q_c) : 0.0f;
+    out.d1[3] = in ? 3.0f * q_c : 0.0f;
+    out.d2[0] = in ? -3.0f * w_a : 0.0f;
+    out.d2[1] = in ? 3.0f * (w_a - w_b) : 0.0f;
+    out.d2[2] = in ? 3.0f * (w_b - w_c) : 0.0f;
+    out.d2[3] = in ? 3.0f * w_c : 0.0f;
+  }
+}
+
+// column m of a pair (m < 4: live spline column, 4: base-activation column), scaled per jet
+struct JetCoefs { float s0, a1, a2, a3, q3; };
+__device__ __forceinline__ JetCoefs jet_coefs(const f32x4& jet, const JetScales& sc) {
+  return {sc.s[0], jet[1] * sc.s[1], jet[2] * sc.s[2], jet[3] * sc.s[3], jet[1] * jet[1] * sc.s[3]};
+}
+__device__ __forceinline__ f32x4 pair_column(float f0, float f1, float f2, const JetCoefs& jc) {
+  return (f32x4){f0 * jc.s0, f1 * jc.a1, f1 * jc.a2, f2 * jc.q3 + f1 * jc.a3};
+}
+
+// One step = 4 points = NT regions of 6 matrix instructions (one row tile each) on the wave's E tile and the planes
+// G.  On entry xr / gr hold the raw rows of step s+1, kp the knots around its pairs, cur / nxt the operands of this
+// step's first two row tiles; the rows of step s+3 are fetched into xr / gr once they have been consumed, and the
+// knots of step s+2 (raw rows xr2) are requested at the end.  Operands are read two regions ahead:
+//   region 0      basis of the pairs of step s+1
+//   region 1      activation, columns 0, 1
+//   region 2      columns 2 .. 4, cut columns 0, 1; fetch the input jets of step s+3
+//   region 3      cut columns 2 .. 4
+//   region 4      every operand of this step has been requested: park the planes of step s+1
+//   region 5      scale and cut the gY rows of step s+1, first output tile; first operands of step s+1
+//   region 6      the second output tile; fetch the gY rows of step s+3; knots of step s+2
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ void wgw_step(f32x16 (&acc)[WgW<C1>::NT][2], const GyTiles32& G, GyTiles32& Gn, TileOps16& cur,
+                                         TileOps16& nxt, f32x4 (&gr)[2][2], f32x4& xr, KnotPre<GEN>& kp, const f32x4& xr2,
+                                         KnotPre<GEN>& kp2, unsigned* sE, const int (&eoff)[WgW<C1>::NT], unsigned* feat,
+                                         unsigned*& prev, const float* knots, const FeatGrid& fg, const JetScales& se,
+                                         const f32x4& tg, const char* __restrict__ xrow3, const char* __restrict__ grow3,
+                                         unsigned xoff, unsigned goff, int O) {
+  constexpr int NT = WgW<C1>::NT, nk = WgW<C1>::nk;
+  static_assert(NT == 7, "the region plan below is written for 7 row tiles");
+  Basis bs;
+  Act av;
+  JetCoefs jc;
+  f32x4 col[5];
+  Planes16 pp[5];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const TileOps16 nx2 = read_wgw_tile<C1>(sE, eoff[(t + 2) % NT]);     // (regions 5, 6: the tile parked in region 4)
+    if (t == 0) basis_from_knots<GEN>(kp, nk, fg, xr[0], bs);
+    if (t == 1) {
+      av = eval_act(ACT, xr[0]);
+      jc = jet_coefs(xr, se);
+      col[0] = pair_column(bs.b[0], bs.d1[0], bs.d2[0], jc);
+      col[1] = pair_column(bs.b[1], bs.d1[1], bs.d2[1], jc);
+    }
+    if (t == 2) {
+      col[2] = pair_column(bs.b[2], bs.d1[2], bs.d2[2], jc);
+      col[3] = pair_column(bs.b[3], bs.d1[3], bs.d2[3], jc);
+      col[4] = pair_column(av.f0, av.f1, av.f2, jc);
+      xr = ld16v(xrow3, xoff);
+      pp[0] = split_jet16(col[0]); pp[1] = split_jet16(col[1]);
+    }
+    if (t == 3) { pp[2] = split_jet16(col[2]); pp[3] = split_jet16(col[3]); pp[4] = split_jet16(col[4]); }
+    if (t == 4) park_wgw<C1>(feat, prev, pp, bs.c0);
+    if (t == 5) split_gy_tile32(gr[0], tg, Gn, 0);
+    if (t == 6) {
+      split_gy_tile32(gr[1], tg, Gn, 1);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) gr[n][e] = ld16v(grow3, goff + (unsigned)(e * O + n * 32) * 16u);
+      kp2 = fetch_knots<GEN>(knots, nk, fg, xr2[0]);
+    }
+    mfma_wgw_tile(acc[t], cur, G);
+    cur = nxt;
+    nxt = nx2;
+    interleave<6, 6>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+bwd_weight_f16w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                       const float* __restrict__ ginfo, float* __restrict__ part, int64_t N, int I, int O,
+                       int64_t chunk_pts, int nx, int ny, int nz, const unsigned* __restrict__ act_in,
+                       const unsigned* __restrict__ cot_in) {
+  using W = WgW<C1>;
+  constexpr int FE = W::FE, NT = W::NT, nk = W::nk;
+  constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  constexpr int kWaveWords = W::wave_words(GEN);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bx, by, bz;                             // blocks that read the same rows are 8 ids apart: one XCD's L2
+  {
+    const int b = blockIdx.x;
+    if (nz % 8 == 0) {
+      const int rr = b >> 3;
+      bx = rr % nx; by = (rr / nx) % ny; bz = (rr / (nx * ny)) * 8 + (b & 7);
+    } else {
+      bx = b % nx; by = (b / nx) % ny; bz = b / (nx * ny);
+    }
+  }
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int i0 = (bx * 4 + wave) * FE, o0 = by * 64;
+  {                                           // the wave's group of 32 features: all equally spaced -> GEN = false
+    const float gi = ginfo[(i0 & ~31) + (lane & 31)];      // takes it; all at least nearly so -> GEN = true
+    const bool all_near = __builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull;
+    const bool all_equal = __builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull;
+    if (!all_near || all_equal == GEN) return;
+  }
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;     // this wave's tile
+  float* sK = reinterpret_cast<float*>(sE + W::TILE);                       // and its FE knot rows
+  const int r = lane & 31, hq = lane >> 5, p_local = lane & 3, f_local = lane >> 2;
+  if constexpr (GEN) {                        // [g_0 x3][the nk knots][g_last x4]
+    for (int idx = lane; idx < FE * KP; idx += 64) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = grid[(size_t)(i0 + f) * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = lane; idx < FE * (nk + 1); idx += 64) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)(i0 + f) * nk + k] : ginfo[i0 + f];
+    }
+  }
+  for (int idx = lane; idx < W::TILE / 4; idx += 64) reinterpret_cast<u32x4*>(sE)[idx] = (u32x4){0u, 0u, 0u, 0u};
+  const float* knots = sK + f_local * KP + (GEN ? 3 : 0);
+  const FeatGrid fg = {grid[(size_t)(i0 + f_local) * nk], grid[(size_t)(i0 + f_local) * nk + nk - 1],
+                       fabsf(ginfo[i0 + f_local])};
+  // scales: gY's jet j by t_j; E's jet j by c / t_j, c = the smallest of (scale that E_j alone could take) * t_j
+  JetScales se;
+  f32x4 tg;
+  float inv_c;
+  {
+    const JetScales eb = expanded_jet_scales(act_in, max_inv_h(ginfo, I, lane));
+    float c = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tg[j] = pow2_scale(__uint_as_float(cot_in[j]));
+      c = fminf(c, eb.s[j] * tg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) se.s[j] = c * rcp_pow2(tg[j]);
+    inv_c = rcp_pow2(c);
+  }
+
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][n][v] = 0.f;
+
+  // N and chunk_pts are multiples of 16: whole pairs of steps
+  const int64_t pbeg = (int64_t)bz * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  if (pbeg >= pend) return;                   // (never with the chunks the host makes: every chunk slot is written)
+  const char* xb = reinterpret_cast<const char*>(a);
+  const char* gb = reinterpret_cast<const char*>(gy);
+  const unsigned xoff = (unsigned)(p_local * I + i0 + f_local) * 16u;
+  const unsigned goff = (unsigned)(2 * hq * O + o0 + r) * 16u;
+  const size_t xstride = (size_t)I * 16, gstride = (size_t)O * 16;         // bytes per point
+
+  // where this lane parks its pair (row 0 of its feature) and where it reads its operands (row tile t)
+  unsigned* feat = sE + (p_local >> 1) * W::HALF + (f_local * W::FROWS) * 4 + (p_local & 1) * 2;
+  int eoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) eoff[t] = hq * W::HALF + W::row_of(32 * t + r) * 4;
+  {
+    f32x4 grA[2][2], grB[2][2], xrA, xrB;     // raw rows of the steps after this one: A = odd steps, B = even steps
+    KnotPre<GEN> kpA, kpB;
+    GyTiles32 GA, GB;
+    unsigned* prev = feat;                    // the rows the pair wrote last
+    // rows past the end of the chunk: any valid rows, fetched (and expanded) but never used
+    auto row_at = [&](int64_t p) { return (p < pend) ? p : pbeg; };
+    {
+      f32x4 g0[2][2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const unsigned off = goff + (unsigned)(e * O + n * 32) * 16u;
+          g0[n][e] = ld16v(gb + pbeg * gstride, off);
+          grA[n][e] = ld16v(gb + row_at(pbeg + 4) * gstride, off);
+          grB[n][e] = ld16v(gb + row_at(pbeg + 8) * gstride, off);
+        }
+      const f32x4 x0 = ld16v(xb + pbeg * xstride, xoff);
+      xrA = ld16v(xb + row_at(pbeg + 4) * xstride, xoff);
+      xrB = ld16v(xb + row_at(pbeg + 8) * xstride, xoff);
+      const KnotPre<GEN> kp0 = fetch_knots<GEN>(knots, nk, fg, x0[0]);
+      Basis bs;
+      basis_from_knots<GEN>(kp0, nk, fg, x0[0], bs);
+      const Act av = eval_act(ACT, x0[0]);
+      const JetCoefs jc = jet_coefs(x0, se);
+      Planes16 pp[5];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) pp[m] = split_jet16(pair_column(bs.b[m], bs.d1[m], bs.d2[m], jc));
+      pp[4] = split_jet16(pair_column(av.f0, av.f1, av.f2, jc));
+      park_wgw<C1>(feat, prev, pp, bs.c0);
+      split_gy_tile32(g0[0], tg, GA, 0);
+      split_gy_tile32(g0[1], tg, GA, 1);
+      kpA = fetch_knots<GEN>(knots, nk, fg, xrA[0]);
+    }
+    TileOps16 cur = read_wgw_tile<C1>(sE, eoff[0]), nxt = read_wgw_tile<C1>(sE, eoff[1]);
+    for (int64_t pb = pbeg; pb < pend; pb += 8) {
+      // even step (planes GA): expands step +1 (xrA, grA, kpA), fetches step +3 into xrA / grA, the knots of step +2
+      wgw_step<C1, ACT, GEN>(acc, GA, GB, cur, nxt, grA, xrA, kpA, xrB, kpB, sE, eoff, feat, prev, knots, fg, se, tg,
+                             xb + row_at(pb + 12) * xstride, gb + row_at(pb + 12) * gstride, xoff, goff, O);
+      // odd step (planes GB): expands step +2 (xrB, grB, kpB), fetches step +4 into xrB / grB, the knots of step +3
+      wgw_step<C1, ACT, GEN>(acc, GB, GA, cur, nxt, grB, xrB, kpB, xrA, kpA, sE, eoff, feat, prev, knots, fg, se, tg,
+                             xb + row_at(pb + 16) * xstride, gb + row_at(pb + 16) * gstride, xoff, goff, O);
+    }
+  }
+  // D[column][output]: register v of this lane is column 32t + 8 (v >> 2) + 4 hq + (v & 3) of output 32n + r
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      float* dst = part + (((size_t)bz * O + o0 + n * 32 + r) * I + i0) * C1 + t * 32 + 4 * hq;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[t][n][4 * q], acc[t][n][4 * q + 1], acc[t][n][4 * q + 2], acc[t][n][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(dst + 8 * q) = v * inv_c;
+      }
+    }
+}
+
+// ==========================================================================================================
 // 12 jets per scalar (5 assets + time: value, 6 first derivatives, 5 second derivatives; the basket model).
 // A scalar's jets are three groups of four slots, and every (point, group) is a "virtual point" with four rows:
 //   group 0: value, d/dx0, d/dx1, d/dx2      group 1: d/dx3, d/dx4, d/dx5, d2/dx0^2      group 2: d2/dx1^2 .. d2/dx4^2
@@ -2131,13 +2499,41 @@ static void bww_f16_launch(const LayerView& L, const float* a, const float* gy, 
                                                       act_in, cot_in);
 }
 
+// Layers whose fp16 weight gradients run on 32 x 32 tiles (bwd_weight_f16w_kernel): chunks of about 512 points
+bool f16_wide_weight_tiles(int D, int D2, const LayerView& L) {
+  if (!f16_eligible(D, D2, L) || L.G != 10 || L.I % 64 != 0) return false;
+  const char* off = getenv("PDEKAN_DISABLE_F16_WIDE");   // A/B switch for tests and profiling
+  return !(off && off[0] == '1');
+}
+
+template <int C1>
+static void bww_f16w_launch(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16, int64_t chunk,
+                            int ny, int nmain, const unsigned* act_in, const unsigned* cot_in, hipStream_t st) {
+  auto kb = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, kActSiLU, false>
+                                : bwd_weight_f16w_kernel<C1, kActIdentity, false>;
+  auto kg = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, kActSiLU, true>
+                                : bwd_weight_f16w_kernel<C1, kActIdentity, true>;
+  const size_t lds_b = (size_t)4 * WgW<C1>::wave_words(false) * 4;
+  const size_t lds_g = (size_t)4 * WgW<C1>::wave_words(true) * 4;
+  allow_lds(kb, lds_b);
+  allow_lds(kg, lds_g);
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  const int nx = L.I / 64;
+  kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
+  kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
+                                                      act_in, cot_in);
+}
+
 // The two variants on the grid of bwd_weight_mfma_kernel (blocks of 4*FE features x 64 outputs x nmain chunks of
 // `chunk` points, N16 and chunk multiples of 16): a block runs in the variant that matches its features' knot rows.
 // act_in / cot_in: per-jet maxima of a and gy (4 words each).
 void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16,
                                   int64_t chunk, int nx, int ny, int nmain, const unsigned* act_in,
                                   const unsigned* cot_in, hipStream_t st) {
-  if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
+  if (f16_wide_weight_tiles(2, 1, L)) bww_f16w_launch<14>(L, a, gy, part, N16, chunk, ny, nmain, act_in, cot_in, st);
+  else if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
   else bww_f16_launch<24, 4>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
 }
 

@@ -104,6 +104,8 @@ void launch_bwd_input_sparse(const LayerView& L, const float* a, const float* gy
 // kan_f16.hip: hidden layers on the fp16 matrix cores with fp32 accuracy (two fp16 pieces per operand, three
 // products), J = 4 jets; for layers whose knot rows are all (nearly) equally spaced - decided on the device
 bool f16_eligible(int D, int D2, const LayerView& L);
+// layers whose fp16 weight gradients take chunks of about 512 points (32 x 32 matrix tiles, no second register set)
+bool f16_wide_weight_tiles(int D, int D2, const LayerView& L);
 size_t f16_wplane_floats(const LayerView& L);
 void launch_absmax(const float* w, int64_t n, unsigned* out, hipStream_t st);               // out[0] = bits of max |w|
 void launch_jet_absmax(const float* t, int64_t elems, unsigned* out4, hipStream_t st);      // per-jet maxima of [elems][4]
@@ -127,7 +129,8 @@ void launch_bwd_weight12_f16(const LayerView& L, const float* a, const float* gy
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);
-int mfma_weight_chunks(int64_t N, const LayerView& L);
+// short_chunks: chunks of about 512 points instead of 4096 (f16_wide_weight_tiles layers)
+int mfma_weight_chunks(int64_t N, const LayerView& L, bool short_chunks = false);
 bool mfma_skinny_weight_eligible(int D, int D2, const LayerView& L);   // 2-input layers: weight gradients only
 int mfma_skinny_weight_chunks(int64_t N, const LayerView& L);
 void launch_bwd_weight_mfma_skinny(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
