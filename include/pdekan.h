@@ -87,6 +87,21 @@ int pdekan_seed_jets(const float* x, int64_t stride_n, int64_t stride_d, int64_t
 int pdekan_basis_dense(const float* grid, const float* x, int64_t n, int32_t in_features, int32_t grid_size,
                        int32_t spline_order, int32_t order, float* out, void* stream);
 
+/* KANLinear.curve2coeff (kan.py:113-143): coeff[out][in][grid_size + 3] = least-squares spline coefficients through
+ * the samples (x[n][i], y[n][i][o]) on grid[in][grid_size + 7], per input feature, the minimal-norm solution where the
+ * samples leave coefficients undetermined (torch.linalg.lstsq's, kan.py:131-133; rank cut at eps * max(n, coeffs)
+ * like its default).  x and y take element strides (update_grid passes a permuted view, kan.py:178-180).
+ * With y = NULL the samples are the layer's own edge functions on its OLD grid,
+ *   y[n][i][o] = sum_c B_c(x[n][i]; old_grid) * old_spline_weight[o][i][c] * old_spline_scaler[o][i]  (scaler NULL: 1)
+ * which is the refit update_grid does after moving the knots (kan.py:173-180, :215) without the [n][in][out] tensor.
+ * Solved in fp64 (normal equations + Jacobi eigen-decomposition per feature); spline_order 3, grid_size <= 20.
+ * grid and old_grid must not alias coeff; no workspace. */
+int pdekan_fit_coefficients(const float* grid, const float* x, int64_t x_stride_n, int64_t x_stride_i, int64_t n,
+                            int32_t in_features, int32_t out_features, int32_t grid_size, int32_t spline_order,
+                            const float* y, int64_t y_stride_n, int64_t y_stride_i, int64_t y_stride_o,
+                            const float* old_grid, const float* old_spline_weight, const float* old_spline_scaler,
+                            float* coeff, void* stream);
+
 /* KANLinear.forward (kan.py:153-166) on jets: y_jet[N][out][J] from
  * x_jet[N][in][J].  With (n_dir, n_second) = (0,0) this is exactly the
  * reference forward; otherwise the derivative slots carry what autograd /

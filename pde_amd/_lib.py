@@ -50,6 +50,11 @@ SIGNATURES = {
     "pdekan_basis_dense": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p]),
+    "pdekan_fit_coefficients": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]),
     "pdekan_layer_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(PdekanLayer), ctypes.c_int64,
                                                        ctypes.c_int32, ctypes.c_int32]),
     "pdekan_layer_forward": (ctypes.c_int, [ctypes.POINTER(PdekanLayer), ctypes.c_void_p, ctypes.c_void_p,

@@ -779,6 +779,184 @@ void launch_basis_dense(const float* x, const float* grid, float* out, int64_t N
   basis_dense_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, grid, out, total, I, G + 2 * kOrder + 1, G + kOrder, order);
 }
 
+// --------------------------------------------------------------------------
+// curve2coeff (efficient_kan/kan.py:113-143): per input feature i the least-squares spline coefficients through the
+// samples (x[p][i], y[p][i][:]), coeff[o][i][:] = argmin_c sum_p (sum_c B_c(x_pi) c - y_pio)^2, the minimal-norm one
+// where the samples leave coefficients undetermined (what the reference's lstsq returns).  One block per feature:
+//   - the dense bases of 256 points at a time in LDS; thread (a, b) adds their products into the Gram matrix
+//     G = B^T B, thread o adds B^T y[:, i, o] into its own right-hand side - both in fp64, in a fixed order;
+//   - cyclic Jacobi rotations diagonalise G (C <= 23) in LDS: G = V diag(lam) V^T;
+//   - coeff = V diag(1 / lam, 0 where lam <= (rcond^2) lam_max) V^T (B^T y): the pseudo-inverse, fp64 throughout,
+//     so the result carries the conditioning of B once (fp64 on the squared condition number), not of an fp32 solver.
+// The samples y are either given (y != nullptr, element strides) or are the layer's own edge functions on its OLD
+// grid, sum_c B_c^old(x_pi) spline_weight[o][i][c] spline_scaler[o][i] (update_grid, kan.py:173-180 and :215): then
+// they are evaluated on the fly from the 4 live old bases and never stored.
+// --------------------------------------------------------------------------
+constexpr int kFitCMax = 24;                 // coefficients per feature: grid_size + 3 <= 23
+constexpr int kFitPts = 256;
+
+struct FitSamples {
+  const float* y; int64_t sn, si, so;        // given samples, or
+  const float* old_grid; const float* old_w; const float* old_scaler;   // the layer before its grid moved
+};
+
+__global__ void __launch_bounds__(256)
+fit_coeff_kernel(const float* __restrict__ x, int64_t xsn, int64_t xsi, int64_t N, int I, int O, int nk,
+                 const float* __restrict__ grid, FitSamples src, double rcond, float* __restrict__ coeff) {
+  const int C = nk - kOrder - 1, i = blockIdx.x, tid = threadIdx.x;
+  __shared__ float sK[32], sKo[32];
+  __shared__ float sB[kFitPts][kFitCMax];                  // dense bases of the tile's points on the new grid
+  __shared__ float sOb[kFitPts][4];                        // live bases on the old grid (0 where the column does not exist)
+  __shared__ int sOc[kFitPts];                             // their first column, clamped so that c .. c+3 exist
+  __shared__ float sWo[kFitCMax][256];                     // old scaled weights of this feature: [c][o]
+  __shared__ double sM[kFitCMax][kFitCMax + 1], sV[kFitCMax][kFitCMax + 1], sInv[kFitCMax];
+  if (tid < nk) {
+    sK[tid] = grid[(size_t)i * nk + tid];
+    if (!src.y) sKo[tid] = src.old_grid[(size_t)i * nk + tid];
+  }
+  double gm[3] = {0.0, 0.0, 0.0};
+  for (int o0 = 0; o0 < O; o0 += 256) {
+    const int o = o0 + tid;
+    const bool o_live = o < O;
+    if (!src.y) {
+      const float sc = (o_live && src.old_scaler) ? src.old_scaler[(size_t)o * I + i] : 1.0f;
+      for (int c = 0; c < C; ++c) sWo[c][tid] = o_live ? src.old_w[((size_t)o * I + i) * C + c] * sc : 0.0f;
+    }
+    double rh[kFitCMax];
+#pragma unroll
+    for (int a = 0; a < kFitCMax; ++a) rh[a] = 0.0;
+    __syncthreads();
+    for (int64_t p0 = 0; p0 < N; p0 += kFitPts) {
+      {
+        const int64_t p = p0 + tid;
+        Basis bs = {};
+        float xv = 0.0f;
+        if (p < N) { xv = x[p * xsn + i * xsi]; eval_basis<false>(sK, nk, xv, bs); }
+#pragma unroll
+        for (int c = 0; c < kFitCMax; ++c) {
+          const int m = c - bs.c0;
+          sB[tid][c] = (p < N && c < C && m >= 0 && m < 4) ? bs.b[m] : 0.0f;
+        }
+        if (!src.y) {
+          Basis bo = {};
+          if (p < N) eval_basis<false>(sKo, nk, xv, bo);
+          const int cc = (p < N) ? (bo.c0 < 0 ? 0 : (bo.c0 > C - 4 ? C - 4 : bo.c0)) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                    // value of column cc + q
+            const int m = cc + q - bo.c0;
+            sOb[tid][q] = (p < N && m >= 0 && m < 4) ? bo.b[m] : 0.0f;
+          }
+          sOc[tid] = cc;
+        }
+      }
+      __syncthreads();
+      const int np = (N - p0 < kFitPts) ? (int)(N - p0) : kFitPts;
+      if (o0 == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int e = tid + 256 * q;
+          if (e < C * C) {
+            const int a = e / C, b = e - a * C;
+            double sum = 0.0;
+            for (int p = 0; p < np; ++p) sum += (double)sB[p][a] * (double)sB[p][b];
+            gm[q] += sum;
+          }
+        }
+      }
+      if (o_live) {
+        for (int p = 0; p < np; ++p) {
+          float yv;
+          if (src.y) {
+            yv = src.y[(p0 + p) * src.sn + i * src.si + o * src.so];
+          } else {
+            const int cc = sOc[p];
+            yv = sOb[p][0] * sWo[cc][tid] + sOb[p][1] * sWo[cc + 1][tid] + sOb[p][2] * sWo[cc + 2][tid] +
+                 sOb[p][3] * sWo[cc + 3][tid];
+          }
+          const double yd = (double)yv;
+#pragma unroll
+          for (int a = 0; a < kFitCMax; ++a) rh[a] += (double)sB[p][a] * yd;
+        }
+      }
+      __syncthreads();
+    }
+    if (o0 == 0) {
+      // G -> sM, V = identity, then cyclic Jacobi sweeps (fixed count: quadratic convergence, C <= 23)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = tid + 256 * q;
+        if (e < C * C) { const int a = e / C, b = e - a * C; sM[a][b] = gm[q]; sV[a][b] = (a == b) ? 1.0 : 0.0; }
+      }
+      __syncthreads();
+      for (int sweep = 0; sweep < 12; ++sweep)
+        for (int pp = 0; pp + 1 < C; ++pp)
+          for (int qq = pp + 1; qq < C; ++qq) {
+            const double app = sM[pp][pp], aqq = sM[qq][qq], apq = sM[pp][qq];
+            double cs = 1.0, sn = 0.0, tt = 0.0;
+            if (fabs(apq) > 1e-300) {
+              const double tau = (aqq - app) / (2.0 * apq);
+              tt = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              cs = 1.0 / sqrt(1.0 + tt * tt);
+              sn = tt * cs;
+            }
+            __syncthreads();
+            if (tid < C) {
+              const int k = tid;
+              const double vkp = sV[k][pp], vkq = sV[k][qq];
+              sV[k][pp] = cs * vkp - sn * vkq;
+              sV[k][qq] = sn * vkp + cs * vkq;
+              if (k != pp && k != qq) {
+                const double akp = sM[k][pp], akq = sM[k][qq];
+                const double n1 = cs * akp - sn * akq, n2 = sn * akp + cs * akq;
+                sM[k][pp] = n1; sM[pp][k] = n1; sM[k][qq] = n2; sM[qq][k] = n2;
+              } else if (k == pp) {
+                sM[pp][pp] = app - tt * apq; sM[pp][qq] = 0.0; sM[qq][pp] = 0.0;
+              } else {
+                sM[qq][qq] = aqq + tt * apq;
+              }
+            }
+            __syncthreads();
+          }
+      double lmax = 0.0;
+      for (int k = 0; k < C; ++k) lmax = fmax(lmax, sM[k][k]);
+      if (tid < C) sInv[tid] = (sM[tid][tid] > rcond * rcond * lmax && sM[tid][tid] > 0.0) ? 1.0 / sM[tid][tid] : 0.0;
+      __syncthreads();
+    }
+    if (o_live) {
+      double tk[kFitCMax];
+#pragma unroll
+      for (int k = 0; k < kFitCMax; ++k) {
+        double sum = 0.0;
+        if (k < C) {
+#pragma unroll
+          for (int a = 0; a < kFitCMax; ++a) sum += (a < C) ? sV[a][k] * rh[a] : 0.0;
+          sum *= sInv[k];
+        }
+        tk[k] = sum;
+      }
+      float* dst = coeff + ((size_t)o * I + i) * C;
+      for (int c = 0; c < C; ++c) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFitCMax; ++k) sum += (k < C) ? sV[c][k] * tk[k] : 0.0;
+        dst[c] = (float)sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool launch_fit_coefficients(const float* x, int64_t xsn, int64_t xsi, int64_t N, int I, int O, int G, const float* grid,
+                             const float* y, int64_t ysn, int64_t ysi, int64_t yso, const float* old_grid,
+                             const float* old_w, const float* old_scaler, float* coeff, hipStream_t st) {
+  if (G + kOrder > kFitCMax - 1) return false;
+  FitSamples src = {y, ysn, ysi, yso, old_grid, old_w, old_scaler};
+  const int C = G + kOrder;
+  const double rcond = 1.1920928955078125e-07 * (double)(N > C ? N : C);   // lstsq's default for fp32: eps * max(m, n)
+  fit_coeff_kernel<<<I, 256, 0, st>>>(x, xsn, xsi, N, I, O, G + 2 * kOrder + 1, grid, src, rcond, coeff);
+  return true;
+}
+
 void launch_grid_info(const LayerView& L, float* ginfo, hipStream_t st) {
   grid_info_kernel<<<(L.I + 63) / 64, 64, 0, st>>>(L.grid, ginfo, L.I, L.nk());
 }

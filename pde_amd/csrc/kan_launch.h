@@ -47,6 +47,11 @@ void launch_gather_jets4(const float* in12, float* out4, int64_t elems, int k, b
                          JetSkip skip = {});
 // out12[e] <- pass k's (value share, first k, time in pass 0, second k); the value shares are summed over k = 0..4
 void launch_scatter_jets4(const float* in4, float* out12, int64_t elems, int k, hipStream_t st, JetSkip skip = {});
+// curve2coeff: coeff[O][I][G+3] from samples x[N][I] (element strides) and either y[N][I][O] (element strides) or,
+// with y = nullptr, the edge functions of the layer (old_w, old_scaler or nullptr) on old_grid; false: grid too fine
+bool launch_fit_coefficients(const float* x, int64_t xsn, int64_t xsi, int64_t N, int I, int O, int G, const float* grid,
+                             const float* y, int64_t ysn, int64_t ysi, int64_t yso, const float* old_grid,
+                             const float* old_w, const float* old_scaler, float* coeff, hipStream_t st);
 void launch_pack_weights(const LayerView& L, float* wp, float* wt, hipStream_t st, float* ginfo_out = nullptr);
 constexpr int kPackLayersMax = 8;
 bool launch_pack_model(const LayerView* layers, int n_layers, float* const* wp, float* const* wt, float* const* ginfo,

@@ -697,6 +697,24 @@ int pdekan_basis_dense(const float* grid, const float* x, int64_t n, int32_t in_
   return check_launch("basis_dense");
 }
 
+int pdekan_fit_coefficients(const float* grid, const float* x, int64_t x_stride_n, int64_t x_stride_i, int64_t n,
+                            int32_t in_features, int32_t out_features, int32_t grid_size, int32_t spline_order,
+                            const float* y, int64_t y_stride_n, int64_t y_stride_i, int64_t y_stride_o,
+                            const float* old_grid, const float* old_spline_weight, const float* old_spline_scaler,
+                            float* coeff, void* stream) {
+  if (!grid || !x || !coeff || n < 1 || in_features < 1 || out_features < 1)
+    return fail(PDEKAN_ERR_ARG, "fit_coefficients: bad arguments");
+  if (spline_order != 3) return fail(PDEKAN_ERR_ARG, "fit_coefficients: spline_order %d unsupported (cubic only)", spline_order);
+  if (grid_size < 1 || grid_size > 20) return fail(PDEKAN_ERR_ARG, "fit_coefficients: grid_size %d unsupported (1..20)", grid_size);
+  if (!y && (!old_grid || !old_spline_weight))
+    return fail(PDEKAN_ERR_ARG, "fit_coefficients: neither samples y nor the layer on its old grid given");
+  if (!pdekan::launch_fit_coefficients(x, x_stride_n, x_stride_i, n, in_features, out_features, grid_size, grid, y,
+                                       y_stride_n, y_stride_i, y_stride_o, old_grid, old_spline_weight,
+                                       old_spline_scaler, coeff, (hipStream_t)stream))
+    return fail(PDEKAN_ERR_ARG, "fit_coefficients: grid_size %d unsupported", grid_size);
+  return check_launch("fit_coefficients");
+}
+
 size_t pdekan_layer_workspace_bytes(const PdekanLayer* layer, int64_t n, int32_t n_dir, int32_t n_second) {
   pdekan::LayerView L;
   if (to_view(layer, L) || n < 1) return 0;

@@ -237,3 +237,41 @@ def basis_dense(x: torch.Tensor, grid: torch.Tensor, grid_size: int, spline_orde
     """``b_splines`` (kan.py:78-111) of ``x [N, in]`` on the GPU kernel, ``[N, in, grid_size + spline_order]``;
     differentiable in ``x`` to any order and usable under ``torch.func`` transforms."""
     return _BasisDense.apply(x, grid, order, grid_size, spline_order)
+
+
+def fit_coefficients(x: torch.Tensor, grid: torch.Tensor, grid_size: int, spline_order: int,
+                     y: Optional[torch.Tensor] = None, old_grid: Optional[torch.Tensor] = None,
+                     old_spline_weight: Optional[torch.Tensor] = None,
+                     old_spline_scaler: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``curve2coeff`` (kan.py:113-143) on the GPU: ``[out, in, grid_size + spline_order]`` least-squares spline
+    coefficients through ``x [N, in]`` and ``y [N, in, out]`` (any strides), solved per feature in fp64 inside one
+    kernel.  With ``y=None`` the samples are the edge functions of the layer given by ``old_grid`` /
+    ``old_spline_weight`` / ``old_spline_scaler`` - the refit of ``update_grid`` (kan.py:173-180, :215) without
+    the ``[N, in, out]`` tensor."""
+    _require_gpu(x, "x")
+    lib = _lib.load()
+    n, in_f = x.shape
+    gd = grid.detach().contiguous()
+    xd = x.detach()
+    if y is not None:
+        yd = y.detach()
+        out_f = yd.shape[2]
+        ys = yd.stride()
+        og = ow = osc = None
+    else:
+        yd, ys = None, (0, 0, 0)
+        og = old_grid.detach().contiguous()
+        ow = old_spline_weight.detach().contiguous()
+        osc = None if old_spline_scaler is None else old_spline_scaler.detach().contiguous()
+        out_f = ow.shape[0]
+    coeff = torch.empty(out_f, in_f, grid_size + spline_order, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pdekan_fit_coefficients(_ptr(gd), _ptr(xd), xd.stride(0), xd.stride(1), n, in_f, out_f, grid_size,
+                                               spline_order, _ptr(yd), ys[0], ys[1], ys[2], _ptr(og), _ptr(ow),
+                                               _ptr(osc), _ptr(coeff), _stream(x.device)))
+    return coeff
+
+
+def fit_on_device(x: torch.Tensor, grid_size: int, spline_order: int) -> bool:
+    """Whether ``fit_coefficients`` takes these samples (float32 on a GPU, cubic splines, at most 20 intervals)."""
+    return x.is_cuda and x.dtype == torch.float32 and spline_order == 3 and 1 <= grid_size <= 20 and x.size(0) > 0

@@ -94,7 +94,10 @@ class KANLinear(torch.nn.Module):
         """Coefficients interpolating samples (kan.py:113-143)."""
         assert x.dim() == 2 and x.size(1) == self.in_features
         assert y.size() == (x.size(0), self.in_features, self.out_features)
-        coeff = fit_coefficients(x, y, self.grid, self.spline_order)
+        if K.fit_on_device(x, self.grid_size, self.spline_order) and y.dtype == torch.float32:
+            coeff = K.fit_coefficients(x, self.grid, self.grid_size, self.spline_order, y=y)   # fp64 solve in one kernel
+        else:
+            coeff = fit_coefficients(x, y, self.grid, self.spline_order)
         assert coeff.size() == (self.out_features, self.in_features, self.grid_size + self.spline_order)
         return coeff
 
@@ -159,10 +162,16 @@ class KANLinear(torch.nn.Module):
         batch = x.size(0)
         k, g = self.spline_order, self.grid_size
 
-        # per-edge spline outputs at the samples, (batch, in, out)
-        bases = self.b_splines(x).permute(1, 0, 2)
-        coeff = self.scaled_spline_weight.permute(1, 2, 0)
-        edge_out = torch.bmm(bases, coeff).permute(1, 0, 2)
+        on_device = K.fit_on_device(x, g, k) and self.grid.is_cuda
+        if on_device:
+            # the refit kernel evaluates the edge functions on the old grid itself: keep the old grid, skip the
+            # (batch, in, out) tensor
+            old_grid = self.grid.clone()
+        else:
+            # per-edge spline outputs at the samples, (batch, in, out)
+            bases = self.b_splines(x).permute(1, 0, 2)
+            coeff = self.scaled_spline_weight.permute(1, 2, 0)
+            edge_out = torch.bmm(bases, coeff).permute(1, 0, 2)
 
         ordered = torch.sort(x, dim=0)[0]
         picks = torch.linspace(0, batch - 1, g + 1, dtype=torch.int64, device=x.device)
@@ -176,7 +185,13 @@ class KANLinear(torch.nn.Module):
         knots = torch.concatenate([below, inner, above], dim=0)
 
         self.grid.copy_(knots.T)
-        self.spline_weight.data.copy_(self.curve2coeff(x, edge_out))
+        if on_device:
+            scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
+            self.spline_weight.data.copy_(K.fit_coefficients(x, self.grid, g, k, old_grid=old_grid,
+                                                             old_spline_weight=self.spline_weight,
+                                                             old_spline_scaler=scaler))
+        else:
+            self.spline_weight.data.copy_(self.curve2coeff(x, edge_out))
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
         """Weight-based stand-in for the paper's activation L1 + entropy terms
