@@ -68,6 +68,9 @@ def kernel_cost(name, widths, grid, n_pts, J):
     if not name.startswith("L"):
         if name == "bs_residual_loss":
             return 0.0, 0.0, PEAK_FP32_TFLOPS, n_pts * 4.0 * (2 * J + widths[0])
+        if name == "small_step":           # whole step of a small model, thread = point: every layer forward and back
+            dense = sum(3 * 2.0 * J * widths[l] * C1 * widths[l + 1] for l in range(len(widths) - 1)) * n_pts
+            return dense, dense * 5.0 / C1, PEAK_FP32_TFLOPS, n_pts * 4.0 * (widths[0] + 1)
         if name == "seed_jets":
             return 0.0, 0.0, PEAK_FP32_TFLOPS, n_pts * 4.0 * widths[0] * (1 + J)
         return 0.0, 0.0, PEAK_FP32_TFLOPS, 0.0
@@ -109,7 +112,7 @@ def roofline_seconds(cost):
 
 
 HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<",
-                 "bwd_weight.mfma_f16x2": "bwd_weight_f16_kernel<", "bwd_input.sparse": "bwd_input_sparse_kernel<",
+                 "bwd_weight.mfma_f16x2": "bwd_weight_f16", "bwd_input.sparse": "bwd_input_sparse_kernel<",
                  "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": "fwd_f16_kernel<",
                  "bwd_input.mfma_f16x2": "bwd_input_f16_kernel<", "head_fused": "head_bs_kernel<"}
 

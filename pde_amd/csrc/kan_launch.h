@@ -91,6 +91,17 @@ void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, i
                     float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st,
                     unsigned* cot_out = nullptr);   // per-jet maxima of ga (4 or 12 words) are combined into cot_out
 
+// kan_small.hip: one Black-Scholes step of a small model (inputs (S, t), one output, layers no wider than 8) in two
+// launches: thread = point through every layer and back, then one reduction / unpack launch
+constexpr int kSmallLayersMax = 4;
+struct SmallGrads { float *base_w, *spline_w, *scaler; };
+bool small_step_eligible(const LayerView* layers, int nl, size_t* lds = nullptr);
+size_t small_step_part_floats(const LayerView* layers, int nl, int64_t N);      // workspace: the blocks' partial sums
+// grads = nullptr: loss / residual only; res_out, loss_out, target may be nullptr
+void launch_small_step(const LayerView* layers, const SmallGrads* grads, int nl, const float* x, int64_t sn, int64_t sd,
+                       const float* target, int64_t N, float sigma, float rate, float inv_n, float* res_out,
+                       float* loss_out, float* part, int accumulate, hipStream_t st);
+
 // kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
 bool sparse_eligible(int D, int D2, const LayerView& L);
 bool sparse_input_grad_eligible(int D, int D2, const LayerView& L);

@@ -786,6 +786,10 @@ size_t pdekan_model_workspace_bytes(const PdekanLayer* layers, int32_t n_layers,
   ModelWs W;
   size_t need = 0;
   carve(P, nullptr, 0, W, &need);
+  if (n_dir == 2 && pdekan::small_step_eligible(P.L.data(), (int)P.L.size())) {   // (the two-launch step's partial sums)
+    const size_t small = pdekan::small_step_part_floats(P.L.data(), (int)P.L.size(), n) * sizeof(float);
+    if (small > need) need = small;
+  }
   return need + 256;
 }
 
@@ -834,11 +838,27 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
   if (P.L.back().O != 1) return fail(PDEKAN_ERR_ARG, "bs_step: the last layer must have one output");
   if (n_global < n) return fail(PDEKAN_ERR_ARG, "bs_step: n_global < n");
   if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
-  ModelWs W;
-  if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   const int nl = (int)P.L.size();
   const float inv_n = 1.0f / (float)n_global;
+  if (P.D == 2 && pdekan::small_step_eligible(P.L.data(), nl)) {
+    // a small model: every layer in one launch, thread = point (no per-point workspace, no micro-batches)
+    // (the size the query function names: the same workspace serves pdekan_model_forward_jet)
+    if (pdekan_model_workspace_bytes(layers, n_layers, n, d, d - 1, micro_batch) - 256 > ws_bytes)
+      return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+    pdekan::SmallGrads sg[pdekan::kSmallLayersMax];
+    for (int l = 0; grads && l < nl; ++l) {
+      if (!grads[l].base_weight || !grads[l].spline_weight || (P.L[l].scaler && !grads[l].spline_scaler))
+        return fail(PDEKAN_ERR_ARG, "gradient pointers missing");
+      sg[l] = {grads[l].base_weight, grads[l].spline_weight, grads[l].spline_scaler};
+    }
+    ProfScope ps(st, "small_step", 0);
+    pdekan::launch_small_step(P.L.data(), grads ? sg : nullptr, nl, x, stride_n, stride_d, target, n, sigma, rate, inv_n,
+                              res_out, loss_out, static_cast<float*>(ws), accumulate, st);
+    return check_launch("bs_step (small model)");
+  }
+  ModelWs W;
+  if (!carve(P, ws, ws_bytes, W, nullptr)) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   const ModelStats S = {W.stats, nl};
   {
     ProfScope ps(st, "pack_weights", 0);

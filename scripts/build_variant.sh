@@ -6,5 +6,5 @@ TAG=$1; shift
 D=pde_amd/build
 mkdir -p pde_amd/variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c pde_amd/csrc/kan_f16.hip -o $D/kan_f16_$TAG.o -I pde_amd/csrc "$@" || exit 1
-hipcc --offload-arch=gfx950 -shared -fPIC -o pde_amd/variants/libpdekan_$TAG.so $D/kan_kernels.o $D/kan_mfma.o $D/kan_head.o $D/kan_sparse.o $D/kan_f16_$TAG.o $D/pdekan_api.o || exit 1
+hipcc --offload-arch=gfx950 -shared -fPIC -o pde_amd/variants/libpdekan_$TAG.so $D/kan_kernels.o $D/kan_mfma.o $D/kan_head.o $D/kan_sparse.o $D/kan_f16_$TAG.o $D/kan_small.o $D/pdekan_api.o || exit 1
 echo pde_amd/variants/libpdekan_$TAG.so

@@ -420,3 +420,55 @@ def test_first_layer_kernel_for_two_inputs(widths, N, monkeypatch):
     assert max_rel(res.cpu(), ref64["res"]) <= TOL
     assert abs(loss - ref64["loss"].item()) <= TOL * abs(ref64["loss"].item())
     assert max_rel(grad.cpu(), flat64) <= TOL
+
+
+@pytest.mark.parametrize("widths,G,N,act", [([2, 5, 1], 5, 10000, torch.nn.SiLU), ([2, 6, 1], 5, 100, torch.nn.Identity),
+                                            ([2, 4, 3, 1], 10, 777, torch.nn.SiLU), ([2, 1], 20, 65, torch.nn.SiLU),
+                                            ([2, 8, 1], 5, 1, torch.nn.Identity), ([2, 3, 2, 2, 1], 5, 300, torch.nn.SiLU)])
+def test_small_model_step_in_two_launches_equals_the_layer_by_layer_step(widths, G, N, act):
+    """Models no wider than 8 take `small_step_kernel` (thread = point through every layer and back) and one
+    reduction launch.  Same residuals, loss and gradients as the layer-by-layer kernels (switched on with
+    PDEKAN_DISABLE_SMALL_STEP=1) and as the fp64 oracle; bitwise the same from run to run; with a target, a
+    moved grid, a layer without its standalone scaler, and gradients accumulated into a second call."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, G, 31 + N % 7, act)
+    if len(widths) > 2:
+        m.layers[1].enable_standalone_scale_spline = False
+        del m.layers[1].spline_scaler
+    gen = torch.Generator().manual_seed(N)
+    x = torch.rand(N, 2, generator=gen)
+    target = 0.1 * torch.randn(N, generator=gen)
+    m = m.cuda()
+    if G == 10:                                           # knot rows that are no longer equally spaced
+        with torch.no_grad():
+            m.layers[0].update_grid(torch.rand(500, 2, generator=gen).cuda() * 1.2 - 0.1)
+    name = "silu" if act is torch.nn.SiLU else "identity"
+    layers64 = O.layers_from_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, dtype=torch.float64)
+    ref = O.pinn_step(x.double(), layers64, name, target=target.double())
+
+    def run():
+        step = BlackScholesStep(m)
+        res = torch.empty(N, device="cuda")
+        loss = step(x.cuda(), target=target.cuda(), residual_out=res)
+        return loss.clone(), res, step.flat_grad.clone(), step
+
+    old = os.environ.get("PDEKAN_DISABLE_SMALL_STEP")
+    try:
+        os.environ["PDEKAN_DISABLE_SMALL_STEP"] = "1"
+        loss_l, res_l, grad_l, _ = run()
+        os.environ["PDEKAN_DISABLE_SMALL_STEP"] = "0"
+        loss_s, res_s, grad_s, step = run()
+        loss_s2, res_s2, grad_s2, _ = run()
+    finally:
+        if old is None:
+            os.environ.pop("PDEKAN_DISABLE_SMALL_STEP", None)
+        else:
+            os.environ["PDEKAN_DISABLE_SMALL_STEP"] = old
+    assert torch.equal(loss_s, loss_s2) and torch.equal(res_s, res_s2) and torch.equal(grad_s, grad_s2)
+    assert max_rel(res_s.cpu(), res_l.cpu()) <= 2e-6 and max_rel(grad_s.cpu(), grad_l.cpu()) <= 5e-6
+    assert abs(loss_s.item() - loss_l.item()) <= 2e-6 * abs(loss_l.item())
+    assert max_rel(res_s.cpu(), ref["res"]) <= TOL
+    assert abs(loss_s.item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    flat_ref = torch.cat([ref["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in KEYS
+                          if ref["grads"][l][k] is not None])
+    assert max_rel(grad_s.cpu(), flat_ref) <= TOL
