@@ -36,6 +36,7 @@
 namespace pdekan {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1114,7 +1115,6 @@ bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy,
 // A wave runs in the variant that matches the knot rows of its group of 32 features (the unit in which
 // bwd_weight_mfma_kernel, launched beside with skip_uniform = 1, leaves blocks out).  Output: part[chunk][O][I][C1].
 // ==========================================================================================================
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GyTiles32 { u32x4 h[2], l[2]; };      // 2 output tiles x (2 points x 4 jets)
 
