@@ -1,10 +1,15 @@
 #!/bin/bash
-# Build pde_amd/variants/libpdekan_TAG.so: the in-tree objects with kan_f16.hip recompiled under extra -D flags.
-#   bash scripts/build_variant.sh TAG -DPDEKAN_X=1 ...
+# Build pde_amd/variants/libpdekan_TAG.so: the in-tree objects with ONE source recompiled under extra -D flags.
+#   bash scripts/build_variant.sh TAG kan_f16 -DPDEKAN_X=1 ...
 # (run python -m pde_amd.build first; bench.py / tests pick a variant up through PDEKAN_LIB)
-TAG=$1; shift
+TAG=$1; SRC=$2; shift; shift
 D=pde_amd/build
 mkdir -p pde_amd/variants
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c pde_amd/csrc/kan_f16.hip -o $D/kan_f16_$TAG.o -I pde_amd/csrc "$@" || exit 1
-hipcc --offload-arch=gfx950 -shared -fPIC -o pde_amd/variants/libpdekan_$TAG.so $D/kan_kernels.o $D/kan_mfma.o $D/kan_head.o $D/kan_sparse.o $D/kan_f16_$TAG.o $D/kan_small.o $D/pdekan_api.o || exit 1
+EXTRA=""; [ "$SRC" = "kan_f16" ] && EXTRA="-fno-slp-vectorize"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA -c pde_amd/csrc/$SRC.hip -o $D/${SRC}_$TAG.o -I pde_amd/csrc "$@" || exit 1
+OBJS=""
+for s in kan_kernels kan_mfma kan_head kan_sparse kan_f16 kan_small pdekan_api; do
+  if [ "$s" = "$SRC" ]; then OBJS="$OBJS $D/${s}_$TAG.o"; else OBJS="$OBJS $D/$s.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o pde_amd/variants/libpdekan_$TAG.so $OBJS || exit 1
 echo pde_amd/variants/libpdekan_$TAG.so
