@@ -3,7 +3,7 @@
 # usage (on the GPU box, from the repo root):  bash scripts/profile_round.sh TAG [WORKLOAD] [STEPS]
 # writes gpurun_out/prof_TAG/{stats,pmc_*}, kernel_stats.csv, pmc_summary.txt (header line = what bench.py checks
 # before quoting HBM traffic from it: workload, points per GPU, digest of the kernel sources) and bench_line.json
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-cfg2}
 STEPS=${3:-30}
 export TMPDIR=/tmp

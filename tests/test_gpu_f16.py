@@ -195,3 +195,26 @@ def test_12_jet_slot_scales_cover_wide_dynamic_ranges(monkeypatch):
         assert max_rel(a[1][..., j].cpu(), b[1][..., j].cpu()) <= 5e-6, ("gx", j)
     for name, u, v in zip(NAMES[2:], a[2:], b[2:]):
         assert max_rel(u.cpu(), v.cpu()) <= 5e-6, name
+
+
+@pytest.mark.parametrize("I,O_,N,knots", [(64, 64, 70000, "default"), (128, 128, 5000, "default"), (64, 128, 4099, "jittered"),
+                                          (192, 64, 2049, "default")])
+def test_weight_gradients_on_wide_tiles_agree_with_the_narrow_tiles(I, O_, N, knots, monkeypatch):
+    """Grid-10 layers whose inputs come in multiples of 64 take their weight gradients on 32 x 32 x 16 matrix tiles
+    (16 features x 64 outputs per wave, 4-point steps, chunks of about 512 points, no second register set); with
+    PDEKAN_DISABLE_F16_WIDE=1 the 16 x 16 x 32 kernel runs (8 features per wave, 4096-point chunks).  Same gradients
+    to fp32 reassociation, every other output bit for bit (only the weight gradients change kernel); many chunks, a
+    ragged last chunk, several feature and output blocks, nearly equally spaced knot rows."""
+    lay = _layer(I, O_, 10, knots, I + O_ + 1)
+    xj, gy = _jets(N, I, O_, N + 1)
+    a = _run(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16_WIDE", "1")
+    b = _run(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16_WIDE")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for name, u, v in zip(NAMES[2:], a[2:], b[2:]):
+        assert max_rel(u.cpu(), v.cpu()) <= 3e-6, (name, max_rel(u.cpu(), v.cpu()))
+    assert not torch.equal(a[3], b[3])
+    a2 = _run(lay, xj, gy)                                 # and bit for bit the same from run to run
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
