@@ -387,7 +387,9 @@ def main():
         impl = dom.split(".")[2] if dom.count(".") >= 2 else ""
         if impl in SPLIT_PRODUCTS:
             roof["note"] = (f"fp32-accurate products out of {SPLIT_PRODUCTS[impl]} 16-bit matrix products each: dense "
-                            f"algorithmic flops against {PEAK_16BIT_MFMA_TFLOPS:.0f} / {SPLIT_PRODUCTS[impl]} TFLOP/s")
+                            f"algorithmic flops against {PEAK_16BIT_MFMA_TFLOPS:.0f} / {SPLIT_PRODUCTS[impl]} TFLOP/s "
+                            "(the nominal peak; on non-zero operands this chip sustains 1543-1703 TFLOP/s of dense fp16 "
+                            "matrix work at 1.73-2.0 GHz, profiles/r03_mfma_power.txt)")
         elif kd["flops"] < kd["dense_flops"]:
             roof["note"] = "fp32 vector ALUs (packed FMA): flops of the 5 live columns per feature only, fp32 vector peak"
             roof["dense_equivalent_tflops"] = kd["dense_flops"] / (kd["avg_ms"] * 1e-3) / 1e12

@@ -192,6 +192,9 @@ def test_points_on_knots_cost_no_more_than_they_cost_the_reference_algorithm(rec
             record_property(f"L{l}.{k}", f"hip {e_hip:.2e} ref32 {e_ref:.2e}")
             print(f"unfiltered 2^20: L{l}.{k}: HIP vs fp64 {e_hip:.3e}; fp32 oracle vs fp64 {e_ref:.3e}")
             assert e_hip <= 2 * e_ref + TOL, (l, k, e_hip, e_ref)
+            # and the absolute bar on these seeded points (measured 1.4e-7 .. 4.6e-7 per tensor; another seed may put a
+            # point on the other side of a jump of the third derivative: the relative bar above is the general one)
+            assert e_hip <= 1e-5, (l, k, e_hip)
             off += n
 
 
