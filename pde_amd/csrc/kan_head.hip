@@ -218,10 +218,16 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
 
 static size_t head_table_bytes(const LayerView& L) { return (size_t)(L.I + 1) * head_row_words(L.C()) * 4; }
 
+constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup
+
+// waves per block: 4 where several blocks still fit a CU beside each other, else as many (up to 4) as one block's LDS
+// holds - a head with 256 inputs at grid 20 keeps 3 gradient tables of 32 KB beside its weights and knots
 static int head_waves(const LayerView& L) {
   const size_t table = head_table_bytes(L);
   if (table * 4 <= 64 * 1024) return 4;
-  if (table * 2 <= 64 * 1024) return 2;
+  const size_t fixed = (size_t)L.I * head_knot_words(L.nk()) * 4 + table + 64;
+  for (int nw = 4; nw > 1; --nw)
+    if (fixed + table * nw <= kLdsPerBlockMax) return nw;
   return 1;
 }
 
@@ -230,8 +236,6 @@ static size_t head_lds_bytes(const LayerView& L) {
   const int nw = head_waves(L);
   return (size_t)L.I * head_knot_words(L.nk()) * 4 + head_table_bytes(L) * (1 + nw) + (size_t)nw * 4;
 }
-
-constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup
 
 // Wide heads on fine grids (256 inputs at grid 48 and up) do not fit the LDS: those take the unfused
 // last-layer kernels + bs_residual_kernel.
