@@ -1097,39 +1097,42 @@ bwd_weight_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy,
 }
 
 // ==========================================================================================================
-// weight gradients on 32 x 32 tiles (v_mfma_f32_32x32x16_f16): grid-10 layers whose inputs come in multiples of 64.
-// A matrix instruction of this shape holds the vector issue port for 8 of its 32 cycles (the 16 x 16 x 32 one for 8
-// of its 16), so the same vector work per flop leaves the matrix pipe half as many issue slots short.
-//   wave  = 16 features x C1 columns (224 = 7 row tiles of 32) x 64 outputs (2 column tiles): 14 accumulator tiles
-//           of 16 registers; block = 4 waves = 64 features; one chunk of points per block
-//   step  = 4 points: K = (point, jet) = 16.  Lane (p = lane & 3, f = lane >> 2) expands its (point, feature) pair,
-//           cuts the 20 scaled jets and parks them in the wave's E tile of the NEXT step (two tiles, used in turn:
-//           the park needs no ordering against this step's operand reads); only the 4 columns written two steps
-//           earlier are cleared.  Tile image: [2 planes][2 point pairs][224 columns][2 points x 4 jets x fp16 = 16
-//           bytes], so lane (r = lane & 31, h = lane >> 5) reads its A operand (column 32t + r, points 2h, 2h + 1)
-//           as one 16-byte word out of a contiguous run: no bank conflicts, no padding.
-//   B     = gY rows of the step's points, outputs 32n + r, from global straight into registers two steps ahead,
-//           cut into planes one step ahead.
-// No second register set for long sums here (the accumulators take 224 registers): a chunk is at most about 512
-// points = 384 chained matrix instructions per accumulator, and the chunks are added in fp32 by the reduction.
+// weight gradients on 32 x 32 tiles (v_mfma_f32_32x32x16_f16).  A matrix instruction of this shape holds the vector
+// issue port for 8 of its 32 cycles (the 16 x 16 x 32 one for 8 of its 16), and a lone wave keeps the pipe full with it
+// (16 x 16 x 32 from one wave: 22 to 27 cycles per instruction).
+//   wave  = FE features x C1 columns = NT row tiles of 32, x 64 outputs (2 column tiles): 2 NT accumulator tiles of 16
+//           registers; block = 4 waves = 4 FE features.  Grid 10: FE = 16 (224 columns, 7 row tiles, 224 accumulator
+//           registers, layers whose inputs come in multiples of 64); grid 20: FE = 8 (192 columns, 6 row tiles, 192).
+//   step  = PTS = 64 / FE points = KS = PTS / 4 k-steps of 16 (point, jet).  Lane (p = lane % PTS, f = lane / PTS)
+//           expands its (point, feature) pair, cuts the 20 scaled jets and parks them in the wave's E tile; only the
+//           4 columns written one step earlier are cleared.  Tile image: [2 planes][PTS / 2 point pairs][FE features]
+//           [C1 + 6 rows][2 points x 4 jets x fp16 = 16 bytes]; the rows of a feature: 3 that take what would be
+//           columns -3 .. -1, the C1 - 1 spline columns, 3 that take the columns past them, the base-activation
+//           column - a pair's 4 live columns go to 4 consecutive rows whatever its interval, with no range checks,
+//           and the rows in between are never read.  Lane (r = lane & 31, h = lane >> 5) reads its A operand of
+//           (row tile t, k-step ks) - column 32t + r, points 4ks + 2h, + 1 - as one 16-byte word.
+//   B     = gY rows of the step's points, outputs 32n + r, from global straight into registers two steps ahead, cut
+//           into planes one step ahead.
+// There is no second register set for long sums (the accumulators take most of the file): every kWwFlushPoints
+// points the accumulators go to the chunk's partial in memory and start again from zero - the first time as plain
+// stores, after that as load, add, store by the lane that owns the word (a partial of a few tens of KB per wave stays
+// in the last-level cache; float atomic adds were measured at twice the time of the whole kernel).
 // A wave runs in the variant that matches the knot rows of its group of 32 features (the unit in which
 // bwd_weight_mfma_kernel, launched beside with skip_uniform = 1, leaves blocks out).  Output: part[chunk][O][I][C1].
 // ==========================================================================================================
+constexpr int kWwFlushPoints = 512;
 
 struct GyTiles32 { u32x4 h[2], l[2]; };      // 2 output tiles x (2 points x 4 jets)
 
-// E tile of a wave: [2 planes][2 point pairs][FE features][20 rows][2 points x 4 jets x fp16 = 16 bytes].  The rows of
-// a feature: 3 that take what would be columns -3 .. -1, the 13 spline columns, 3 that take columns 13 .. 15, the
-// base-activation column - so a pair's 4 live columns go to 4 consecutive rows whatever its interval, with no
-// range checks, and the rows in between are never read.
-template <int C1>
+template <int C1, int FE>
 struct WgW {
-  static constexpr int FE = 16, COLS = FE * C1, NT = COLS / 32, nk = C1 + 3;
+  static constexpr int COLS = FE * C1, NT = COLS / 32, nk = C1 + 3;
+  static constexpr int PTS = 64 / FE, KS = PTS / 4, NR = NT * KS;      // points per step, k-steps, regions per step
   static constexpr int FROWS = C1 + 6;                     // rows per feature
   static constexpr int HALF = FE * FROWS * 4;              // words: one pair of points of every row
-  static constexpr int PLANE = 2 * HALF;
+  static constexpr int PLANE = (PTS / 2) * HALF;
   static constexpr int TILE = 2 * PLANE;
-  static_assert(COLS % 32 == 0, "whole row tiles of 32 columns");
+  static_assert(COLS % 32 == 0 && (FE == 16 || FE == 8), "whole row tiles of 32 columns; 4 or 8 points per step");
   static constexpr int wave_words(bool gen) { return TILE + FE * (gen ? kKnotPadN : kKnotPadU); }
   // row of expanded column col = f * C1 + c of the wave (c = C1 - 1: base column)
   static __host__ __device__ constexpr int row_of(int col) {
@@ -1138,9 +1141,9 @@ struct WgW {
 };
 
 // clear the rows a pair wrote one step earlier (at prev), write the 4 live columns c0 .. c0+3 and the base column
-template <int C1>
+template <int C1, int FE>
 __device__ __forceinline__ void park_wgw(unsigned* feat, unsigned*& prev, const Planes16 (&pp)[5], int c0) {
-  constexpr int PL = WgW<C1>::PLANE;
+  constexpr int PL = WgW<C1, FE>::PLANE;
   const u32x2 zero = {0u, 0u};
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -1153,16 +1156,16 @@ __device__ __forceinline__ void park_wgw(unsigned* feat, unsigned*& prev, const 
     *reinterpret_cast<u32x2*>(dst + m * 4) = pp[m].h;
     *reinterpret_cast<u32x2*>(dst + m * 4 + PL) = pp[m].l;
   }
-  *reinterpret_cast<u32x2*>(feat + (WgW<C1>::FROWS - 1) * 4) = pp[4].h;
-  *reinterpret_cast<u32x2*>(feat + (WgW<C1>::FROWS - 1) * 4 + PL) = pp[4].l;
+  *reinterpret_cast<u32x2*>(feat + (WgW<C1, FE>::FROWS - 1) * 4) = pp[4].h;
+  *reinterpret_cast<u32x2*>(feat + (WgW<C1, FE>::FROWS - 1) * 4 + PL) = pp[4].l;
   prev = dst;
 }
 
-template <int C1>
+template <int C1, int FE>
 __device__ __forceinline__ TileOps16 read_wgw_tile(const unsigned* sE, int off) {
   TileOps16 o;
   o.h = *reinterpret_cast<const u32x4*>(sE + off);
-  o.l = *reinterpret_cast<const u32x4*>(sE + off + WgW<C1>::PLANE);
+  o.l = *reinterpret_cast<const u32x4*>(sE + off + WgW<C1, FE>::PLANE);
   return o;
 }
 
@@ -1256,60 +1259,73 @@ __device__ __forceinline__ f32x4 pair_column(float f0, float f1, float f2, const
   return (f32x4){f0 * jc.s0, f1 * jc.a1, f1 * jc.a2, f2 * jc.q3 + f1 * jc.a3};
 }
 
-// One step = 4 points = NT regions of 6 matrix instructions (one row tile each) on the wave's E tile and the planes
-// G.  On entry xr / gr hold the raw rows of step s+1, kp the knots around its pairs, cur / nxt the operands of this
-// step's first two row tiles; the rows of step s+3 are fetched into xr / gr once they have been consumed, and the
-// knots of step s+2 (raw rows xr2) are requested at the end.  Operands are read two regions ahead:
+// One step = PTS points = NR regions of 6 matrix instructions, region q = (row tile q / KS, k-step q % KS), on the
+// wave's E tile and the planes G.  On entry xr / gr hold the raw rows of step s+1, kp the knots around its pairs,
+// cur / nxt the operands of this step's first two regions; the rows of step s+3 are fetched into xr / gr once they
+// have been consumed, and the knots of step s+2 (raw rows xr2) are requested at the end.  Operands are read two
+// regions ahead:
 //   region 0      basis of the pairs of step s+1
 //   region 1      activation, columns 0, 1
 //   region 2      columns 2 .. 4, cut columns 0, 1; fetch the input jets of step s+3
 //   region 3      cut columns 2 .. 4
-//   region 4      every operand of this step has been requested: park the planes of step s+1
-//   region 5      scale and cut the gY rows of step s+1, first output tile; first operands of step s+1
-//   region 6      the second output tile; fetch the gY rows of step s+3; knots of step s+2
-template <int C1, int ACT, bool GEN>
-__device__ __forceinline__ void wgw_step(f32x16 (&acc)[WgW<C1>::NT][2], const GyTiles32& G, GyTiles32& Gn, TileOps16& cur,
-                                         TileOps16& nxt, f32x4 (&gr)[2][2], f32x4& xr, KnotPre<GEN>& kp, const f32x4& xr2,
-                                         KnotPre<GEN>& kp2, unsigned* sE, const int (&eoff)[WgW<C1>::NT], unsigned* feat,
+//   region NR-3   every operand of this step has been requested: park the planes of step s+1; the reads of the
+//                 last two regions go to step s+1
+//   regions G0 .. scale and cut the gY rows of step s+1, one (k-step, output tile) each (G0 = NR-2, or 4 with two
+//                 k-steps); the last of them fetches the gY rows of step s+3
+//   region NR-1   knots of step s+2
+template <int C1, int FE, int ACT, bool GEN, int NT = WgW<C1, FE>::NT, int KS = WgW<C1, FE>::KS>
+__device__ __forceinline__ void wgw_step(f32x16 (&acc)[NT][2], const GyTiles32 (&G)[KS],
+                                         GyTiles32 (&Gn)[KS], TileOps16& cur, TileOps16& nxt,
+                                         f32x4 (&gr)[KS][2][2], f32x4& xr, KnotPre<GEN>& kp, const f32x4& xr2,
+                                         KnotPre<GEN>& kp2, unsigned* sE, const int (&eoff)[NT], unsigned* feat,
                                          unsigned*& prev, const float* knots, const FeatGrid& fg, const JetScales& se,
                                          const f32x4& tg, const char* __restrict__ xrow3, const char* __restrict__ grow3,
                                          unsigned xoff, unsigned goff, int O) {
-  constexpr int NT = WgW<C1>::NT, nk = WgW<C1>::nk;
-  static_assert(NT == 7, "the region plan below is written for 7 row tiles");
+  using W = WgW<C1, FE>;
+  constexpr int NR = W::NR, nk = W::nk;
+  constexpr int G0 = (KS == 1) ? NR - 2 : 4, NPIECE = 2 * KS;
+  static_assert(NR >= 7 && G0 + NPIECE <= NR, "the region plan below");
   Basis bs;
   Act av;
   JetCoefs jc;
   f32x4 col[5];
   Planes16 pp[5];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const TileOps16 nx2 = read_wgw_tile<C1>(sE, eoff[(t + 2) % NT]);     // (regions 5, 6: the tile parked in region 4)
-    if (t == 0) basis_from_knots<GEN>(kp, nk, fg, xr[0], bs);
-    if (t == 1) {
+  for (int q = 0; q < NR; ++q) {
+    const int t = q / KS, ks = q % KS;
+    const int q2 = (q + 2) % NR;                           // (the last two regions: the tile parked in region NR-3)
+    const TileOps16 nx2 = read_wgw_tile<C1, FE>(sE, eoff[q2 / KS] + (q2 % KS) * 2 * W::HALF);
+    if (q == 0) basis_from_knots<GEN>(kp, nk, fg, xr[0], bs);
+    if (q == 1) {
       av = eval_act(ACT, xr[0]);
       jc = jet_coefs(xr, se);
       col[0] = pair_column(bs.b[0], bs.d1[0], bs.d2[0], jc);
       col[1] = pair_column(bs.b[1], bs.d1[1], bs.d2[1], jc);
     }
-    if (t == 2) {
+    if (q == 2) {
       col[2] = pair_column(bs.b[2], bs.d1[2], bs.d2[2], jc);
       col[3] = pair_column(bs.b[3], bs.d1[3], bs.d2[3], jc);
       col[4] = pair_column(av.f0, av.f1, av.f2, jc);
       xr = ld16v(xrow3, xoff);
       pp[0] = split_jet16(col[0]); pp[1] = split_jet16(col[1]);
     }
-    if (t == 3) { pp[2] = split_jet16(col[2]); pp[3] = split_jet16(col[3]); pp[4] = split_jet16(col[4]); }
-    if (t == 4) park_wgw<C1>(feat, prev, pp, bs.c0);
-    if (t == 5) split_gy_tile32(gr[0], tg, Gn, 0);
-    if (t == 6) {
-      split_gy_tile32(gr[1], tg, Gn, 1);
+    if (q == 3) { pp[2] = split_jet16(col[2]); pp[3] = split_jet16(col[3]); pp[4] = split_jet16(col[4]); }
+    if (q == NR - 3) park_wgw<C1, FE>(feat, prev, pp, bs.c0);
+    if (q >= G0 && q < G0 + NPIECE) {
+      const int piece = q - G0, pk = piece / 2, pn = piece % 2;
+      split_gy_tile32(gr[pk][pn], tg, Gn[pk], pn);
+      if (piece == NPIECE - 1) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+        for (int k2 = 0; k2 < KS; ++k2)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) gr[n][e] = ld16v(grow3, goff + (unsigned)(e * O + n * 32) * 16u);
-      kp2 = fetch_knots<GEN>(knots, nk, fg, xr2[0]);
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              gr[k2][n][e] = ld16v(grow3, goff + (unsigned)((4 * k2 + e) * O + n * 32) * 16u);
+      }
     }
-    mfma_wgw_tile(acc[t], cur, G);
+    if (q == NR - 1) kp2 = fetch_knots<GEN>(knots, nk, fg, xr2[0]);
+    mfma_wgw_tile(acc[t], cur, G[ks]);
     cur = nxt;
     nxt = nx2;
     interleave<6, 6>();
@@ -1317,14 +1333,43 @@ __device__ __forceinline__ void wgw_step(f32x16 (&acc)[WgW<C1>::NT][2], const Gy
   }
 }
 
-template <int C1, int ACT, bool GEN>
+// the accumulators of a wave -> the chunk's partial (first: plain stores; later: load, add, store), then zero
+template <int C1, int NT>
+__device__ __forceinline__ void flush_wgw(f32x16 (&acc)[NT][2], float* dst0, int I, float inv_c, bool first) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      float* dst = dst0 + ((size_t)n * 32 * I) * C1 + t * 32;
+      if (first) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[t][n][4 * q], acc[t][n][4 * q + 1], acc[t][n][4 * q + 2], acc[t][n][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(dst + 8 * q) = v * inv_c;
+        }
+      } else {
+        f32x4 old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4*>(dst + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[t][n][4 * q], acc[t][n][4 * q + 1], acc[t][n][4 * q + 2], acc[t][n][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(dst + 8 * q) = old[q] + v * inv_c;
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][n][v] = 0.f;
+    }
+}
+
+template <int C1, int FE, int ACT, bool GEN>
 __global__ void __launch_bounds__(256, 1)
 bwd_weight_f16w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
                        const float* __restrict__ ginfo, float* __restrict__ part, int64_t N, int I, int O,
                        int64_t chunk_pts, int nx, int ny, int nz, const unsigned* __restrict__ act_in,
                        const unsigned* __restrict__ cot_in) {
-  using W = WgW<C1>;
-  constexpr int FE = W::FE, NT = W::NT, nk = W::nk;
+  using W = WgW<C1, FE>;
+  constexpr int NT = W::NT, KS = W::KS, PTS = W::PTS, nk = W::nk;
   constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
   constexpr int kWaveWords = W::wave_words(GEN);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1340,15 +1385,16 @@ bwd_weight_f16w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
   }
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int i0 = (bx * 4 + wave) * FE, o0 = by * 64;
-  {                                           // the wave's group of 32 features: all equally spaced -> GEN = false
-    const float gi = ginfo[(i0 & ~31) + (lane & 31)];      // takes it; all at least nearly so -> GEN = true
+  {                                           // the wave's group of SEL features: all equally spaced -> GEN = false
+    constexpr int SEL = (FE == 16) ? 32 : 16;              // takes it; all at least nearly so -> GEN = true
+    const float gi = ginfo[(i0 & ~(SEL - 1)) + (lane & (SEL - 1))];
     const bool all_near = __builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull;
     const bool all_equal = __builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull;
     if (!all_near || all_equal == GEN) return;
   }
   unsigned* sE = reinterpret_cast<unsigned*>(smem) + wave * kWaveWords;     // this wave's tile
   float* sK = reinterpret_cast<float*>(sE + W::TILE);                       // and its FE knot rows
-  const int r = lane & 31, hq = lane >> 5, p_local = lane & 3, f_local = lane >> 2;
+  const int r = lane & 31, hq = lane >> 5, p_local = lane % PTS, f_local = lane / PTS;
   if constexpr (GEN) {                        // [g_0 x3][the nk knots][g_last x4]
     for (int idx = lane; idx < FE * KP; idx += 64) {
       const int f = idx / KP, k = idx - f * KP - 3;
@@ -1392,39 +1438,47 @@ bwd_weight_f16w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
   // N and chunk_pts are multiples of 16: whole pairs of steps
   const int64_t pbeg = (int64_t)bz * chunk_pts;
   const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
-  if (pbeg >= pend) return;                   // (never with the chunks the host makes: every chunk slot is written)
   const char* xb = reinterpret_cast<const char*>(a);
   const char* gb = reinterpret_cast<const char*>(gy);
   const unsigned xoff = (unsigned)(p_local * I + i0 + f_local) * 16u;
   const unsigned goff = (unsigned)(2 * hq * O + o0 + r) * 16u;
   const size_t xstride = (size_t)I * 16, gstride = (size_t)O * 16;         // bytes per point
+  // D[column][output]: register v of this lane is column 32t + 8 (v >> 2) + 4 hq + (v & 3) of output 32n + r
+  float* const pdst = part + (((size_t)bz * O + o0 + r) * I + i0) * C1 + 4 * hq;
 
-  // where this lane parks its pair (row 0 of its feature) and where it reads its operands (row tile t)
+  if (pbeg >= pend) {                         // a chunk slot past the last point: zeros
+    flush_wgw<C1, NT>(acc, pdst, I, inv_c, true);
+    return;
+  }
+
+  // where this lane parks its pair (row 0 of its feature) and where it reads its operands (row tile t, k-step 0)
   unsigned* feat = sE + (p_local >> 1) * W::HALF + (f_local * W::FROWS) * 4 + (p_local & 1) * 2;
   int eoff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) eoff[t] = hq * W::HALF + W::row_of(32 * t + r) * 4;
   {
-    f32x4 grA[2][2], grB[2][2], xrA, xrB;     // raw rows of the steps after this one: A = odd steps, B = even steps
+    f32x4 grA[KS][2][2], grB[KS][2][2], xrA, xrB;   // raw rows of the steps after this one: A = odd steps, B = even steps
     KnotPre<GEN> kpA, kpB;
-    GyTiles32 GA, GB;
+    GyTiles32 GA[KS], GB[KS];
     unsigned* prev = feat;                    // the rows the pair wrote last
     // rows past the end of the chunk: any valid rows, fetched (and expanded) but never used
     auto row_at = [&](int64_t p) { return (p < pend) ? p : pbeg; };
     {
-      f32x4 g0[2][2];
+      f32x4 g0[KS][2][2];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int k2 = 0; k2 < KS; ++k2)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const unsigned off = goff + (unsigned)(e * O + n * 32) * 16u;
-          g0[n][e] = ld16v(gb + pbeg * gstride, off);
-          grA[n][e] = ld16v(gb + row_at(pbeg + 4) * gstride, off);
-          grB[n][e] = ld16v(gb + row_at(pbeg + 8) * gstride, off);
-        }
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned off = goff + (unsigned)((4 * k2 + e) * O + n * 32) * 16u;
+            g0[k2][n][e] = ld16v(gb + pbeg * gstride, off);
+            grA[k2][n][e] = ld16v(gb + row_at(pbeg + PTS) * gstride, off);
+            grB[k2][n][e] = ld16v(gb + row_at(pbeg + 2 * PTS) * gstride, off);
+          }
       const f32x4 x0 = ld16v(xb + pbeg * xstride, xoff);
-      xrA = ld16v(xb + row_at(pbeg + 4) * xstride, xoff);
-      xrB = ld16v(xb + row_at(pbeg + 8) * xstride, xoff);
+      xrA = ld16v(xb + row_at(pbeg + PTS) * xstride, xoff);
+      xrB = ld16v(xb + row_at(pbeg + 2 * PTS) * xstride, xoff);
       const KnotPre<GEN> kp0 = fetch_knots<GEN>(knots, nk, fg, x0[0]);
       Basis bs;
       basis_from_knots<GEN>(kp0, nk, fg, x0[0], bs);
@@ -1434,33 +1488,31 @@ bwd_weight_f16w_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
 #pragma unroll
       for (int m = 0; m < 4; ++m) pp[m] = split_jet16(pair_column(bs.b[m], bs.d1[m], bs.d2[m], jc));
       pp[4] = split_jet16(pair_column(av.f0, av.f1, av.f2, jc));
-      park_wgw<C1>(feat, prev, pp, bs.c0);
-      split_gy_tile32(g0[0], tg, GA, 0);
-      split_gy_tile32(g0[1], tg, GA, 1);
+      park_wgw<C1, FE>(feat, prev, pp, bs.c0);
+#pragma unroll
+      for (int k2 = 0; k2 < KS; ++k2) {
+        split_gy_tile32(g0[k2][0], tg, GA[k2], 0);
+        split_gy_tile32(g0[k2][1], tg, GA[k2], 1);
+      }
       kpA = fetch_knots<GEN>(knots, nk, fg, xrA[0]);
     }
-    TileOps16 cur = read_wgw_tile<C1>(sE, eoff[0]), nxt = read_wgw_tile<C1>(sE, eoff[1]);
-    for (int64_t pb = pbeg; pb < pend; pb += 8) {
-      // even step (planes GA): expands step +1 (xrA, grA, kpA), fetches step +3 into xrA / grA, the knots of step +2
-      wgw_step<C1, ACT, GEN>(acc, GA, GB, cur, nxt, grA, xrA, kpA, xrB, kpB, sE, eoff, feat, prev, knots, fg, se, tg,
-                             xb + row_at(pb + 12) * xstride, gb + row_at(pb + 12) * gstride, xoff, goff, O);
-      // odd step (planes GB): expands step +2 (xrB, grB, kpB), fetches step +4 into xrB / grB, the knots of step +3
-      wgw_step<C1, ACT, GEN>(acc, GB, GA, cur, nxt, grB, xrB, kpB, xrA, kpA, sE, eoff, feat, prev, knots, fg, se, tg,
-                             xb + row_at(pb + 16) * xstride, gb + row_at(pb + 16) * gstride, xoff, goff, O);
+    TileOps16 cur = read_wgw_tile<C1, FE>(sE, eoff[0]);
+    TileOps16 nxt = read_wgw_tile<C1, FE>(sE, (KS == 1) ? eoff[1] : eoff[0] + 2 * W::HALF);
+    bool first = true;
+    for (int64_t pb = pbeg; pb < pend;) {
+      const int64_t pstop = (pb + kWwFlushPoints < pend) ? pb + kWwFlushPoints : pend;
+      for (; pb < pstop; pb += 2 * PTS) {
+        // even step (planes GA): expands step +1 (xrA, grA, kpA), fetches step +3 into xrA / grA, the knots of step +2
+        wgw_step<C1, FE, ACT, GEN>(acc, GA, GB, cur, nxt, grA, xrA, kpA, xrB, kpB, sE, eoff, feat, prev, knots, fg, se, tg,
+                                   xb + row_at(pb + 3 * PTS) * xstride, gb + row_at(pb + 3 * PTS) * gstride, xoff, goff, O);
+        // odd step (planes GB): expands step +2 (xrB, grB, kpB), fetches step +4 into xrB / grB, the knots of step +3
+        wgw_step<C1, FE, ACT, GEN>(acc, GB, GA, cur, nxt, grB, xrB, kpB, xrA, kpA, sE, eoff, feat, prev, knots, fg, se, tg,
+                                   xb + row_at(pb + 4 * PTS) * xstride, gb + row_at(pb + 4 * PTS) * gstride, xoff, goff, O);
+      }
+      flush_wgw<C1, NT>(acc, pdst, I, inv_c, first);
+      first = false;
     }
   }
-  // D[column][output]: register v of this lane is column 32t + 8 (v >> 2) + 4 hq + (v & 3) of output 32n + r
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      float* dst = part + (((size_t)bz * O + o0 + n * 32 + r) * I + i0) * C1 + t * 32 + 4 * hq;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = {acc[t][n][4 * q], acc[t][n][4 * q + 1], acc[t][n][4 * q + 2], acc[t][n][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(dst + 8 * q) = v * inv_c;
-      }
-    }
 }
 
 // ==========================================================================================================
@@ -2499,27 +2551,29 @@ static void bww_f16_launch(const LayerView& L, const float* a, const float* gy, 
                                                       act_in, cot_in);
 }
 
-// Layers whose fp16 weight gradients run on 32 x 32 tiles (bwd_weight_f16w_kernel): chunks of about 512 points
+// Layers whose fp16 weight gradients run on 32 x 32 tiles (bwd_weight_f16w_kernel): blocks of 64 features at grid 10,
+// of 32 at grid 20
 bool f16_wide_weight_tiles(int D, int D2, const LayerView& L) {
-  if (!f16_eligible(D, D2, L) || L.G != 10 || L.I % 64 != 0) return false;
+  if (!f16_eligible(D, D2, L)) return false;
+  if (!((L.G == 10 && L.I % 64 == 0) || (L.G == 20 && L.I % 32 == 0))) return false;
   const char* off = getenv("PDEKAN_DISABLE_F16_WIDE");   // A/B switch for tests and profiling
   return !(off && off[0] == '1');
 }
 
-template <int C1>
+template <int C1, int FE>
 static void bww_f16w_launch(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16, int64_t chunk,
                             int ny, int nmain, const unsigned* act_in, const unsigned* cot_in, hipStream_t st) {
-  auto kb = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, kActSiLU, false>
-                                : bwd_weight_f16w_kernel<C1, kActIdentity, false>;
-  auto kg = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, kActSiLU, true>
-                                : bwd_weight_f16w_kernel<C1, kActIdentity, true>;
-  const size_t lds_b = (size_t)4 * WgW<C1>::wave_words(false) * 4;
-  const size_t lds_g = (size_t)4 * WgW<C1>::wave_words(true) * 4;
+  auto kb = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, FE, kActSiLU, false>
+                                : bwd_weight_f16w_kernel<C1, FE, kActIdentity, false>;
+  auto kg = (L.act == kActSiLU) ? bwd_weight_f16w_kernel<C1, FE, kActSiLU, true>
+                                : bwd_weight_f16w_kernel<C1, FE, kActIdentity, true>;
+  const size_t lds_b = (size_t)4 * WgW<C1, FE>::wave_words(false) * 4;
+  const size_t lds_g = (size_t)4 * WgW<C1, FE>::wave_words(true) * 4;
   allow_lds(kb, lds_b);
   allow_lds(kg, lds_g);
   const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
-  const int nx = L.I / 64;
+  const int nx = L.I / (4 * FE);
   kb<<<(unsigned)(nx * ny * nmain), 256, lds_b, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
                                                       act_in, cot_in);
   kg<<<(unsigned)(nx * ny * nmain), 256, lds_g, st>>>(a4, g4, L.grid, L.ginfo, part, N16, L.I, L.O, chunk, nx, ny, nmain,
@@ -2532,8 +2586,10 @@ static void bww_f16w_launch(const LayerView& L, const float* a, const float* gy,
 void launch_bwd_weight_f16_blocks(const LayerView& L, const float* a, const float* gy, float* part, int64_t N16,
                                   int64_t chunk, int nx, int ny, int nmain, const unsigned* act_in,
                                   const unsigned* cot_in, hipStream_t st) {
-  if (f16_wide_weight_tiles(2, 1, L)) bww_f16w_launch<14>(L, a, gy, part, N16, chunk, ny, nmain, act_in, cot_in, st);
-  else if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
+  if (f16_wide_weight_tiles(2, 1, L)) {
+    if (L.G == 10) bww_f16w_launch<14, 16>(L, a, gy, part, N16, chunk, ny, nmain, act_in, cot_in, st);
+    else bww_f16w_launch<24, 8>(L, a, gy, part, N16, chunk, ny, nmain, act_in, cot_in, st);
+  } else if (L.G == 10) bww_f16_launch<14, 8>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
   else bww_f16_launch<24, 4>(L, a, gy, part, N16, chunk, nx, ny, nmain, act_in, cot_in, st);
 }
 

@@ -145,8 +145,7 @@ void launch_bwd_weight12_f16(const LayerView& L, const float* a, const float* gy
 
 // kan_mfma.hip: dense f32-MFMA path for wide hidden layers (J = 4 jets)
 bool mfma_eligible(int D, int D2, const LayerView& L);
-// short_chunks: chunks of about 512 points instead of 4096 (f16_wide_weight_tiles layers)
-int mfma_weight_chunks(int64_t N, const LayerView& L, bool short_chunks = false);
+int mfma_weight_chunks(int64_t N, const LayerView& L);
 bool mfma_skinny_weight_eligible(int D, int D2, const LayerView& L);   // 2-input layers: weight gradients only
 int mfma_skinny_weight_chunks(int64_t N, const LayerView& L);
 void launch_bwd_weight_mfma_skinny(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,

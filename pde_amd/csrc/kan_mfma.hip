@@ -1033,12 +1033,12 @@ bool mfma_eligible(int D, int D2, const LayerView& L) {
 // Chunks of points per weight-gradient launch: enough blocks to fill the chip, and short enough that a chunk's
 // running fp32 sums stay accurate (a 2^19-point chunk loses 3e-5 against an fp64 sum, a 4096-point one 2e-6; the
 // chunks themselves are added in 64 interleaved running sums by sum_partials_kernel), within 4 GiB of partial sums.
-int mfma_weight_chunks(int64_t N, const LayerView& L, bool short_chunks) {
+int mfma_weight_chunks(int64_t N, const LayerView& L) {
   MfmaCfg c;
   cfg_for(L.G, c);
   const int per_chunk = (L.I / (4 * c.kiw)) * (L.O / 64);
   int64_t want = (512 + per_chunk - 1) / per_chunk;
-  int64_t chunk_pts = short_chunks ? 512 : 4096;
+  int64_t chunk_pts = 4096;
   if (const char* e = getenv("PDEKAN_WEIGHT_CHUNK_POINTS")) {          // experiments: 512 .. 2^20 points per chunk
     const long v = atol(e);
     if (v >= 512 && v <= (1 << 20)) chunk_pts = v;

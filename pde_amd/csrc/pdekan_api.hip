@@ -122,7 +122,7 @@ struct Carver {
 };
 
 int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
-  if (pdekan::mfma_eligible(D, D2, L)) return pdekan::mfma_weight_chunks(n, L, pdekan::f16_wide_weight_tiles(D, D2, L));
+  if (pdekan::mfma_eligible(D, D2, L)) return pdekan::mfma_weight_chunks(n, L);
   if (pdekan::mfma_skinny_weight_eligible(D, D2, L)) return pdekan::mfma_skinny_weight_chunks(n, L);
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }

@@ -197,15 +197,19 @@ def test_12_jet_slot_scales_cover_wide_dynamic_ranges(monkeypatch):
         assert max_rel(u.cpu(), v.cpu()) <= 5e-6, name
 
 
-@pytest.mark.parametrize("I,O_,N,knots", [(64, 64, 70000, "default"), (128, 128, 5000, "default"), (64, 128, 4099, "jittered"),
-                                          (192, 64, 2049, "default")])
-def test_weight_gradients_on_wide_tiles_agree_with_the_narrow_tiles(I, O_, N, knots, monkeypatch):
-    """Grid-10 layers whose inputs come in multiples of 64 take their weight gradients on 32 x 32 x 16 matrix tiles
-    (16 features x 64 outputs per wave, 4-point steps, chunks of about 512 points, no second register set); with
-    PDEKAN_DISABLE_F16_WIDE=1 the 16 x 16 x 32 kernel runs (8 features per wave, 4096-point chunks).  Same gradients
-    to fp32 reassociation, every other output bit for bit (only the weight gradients change kernel); many chunks, a
-    ragged last chunk, several feature and output blocks, nearly equally spaced knot rows."""
-    lay = _layer(I, O_, 10, knots, I + O_ + 1)
+@pytest.mark.parametrize("I,O_,G,N,knots", [(64, 64, 10, 70000, "default"), (128, 128, 10, 5000, "default"),
+                                            (64, 128, 10, 4099, "jittered"), (192, 64, 10, 2049, "default"),
+                                            (64, 64, 20, 70000, "default"), (32, 128, 20, 9000, "jittered"),
+                                            (96, 64, 20, 2049, "default"), (256, 256, 20, 4640, "default")])
+def test_weight_gradients_on_wide_tiles_agree_with_the_narrow_tiles(I, O_, G, N, knots, monkeypatch):
+    """Grid-10 layers whose inputs come in multiples of 64 (grid-20 layers: of 32) take their weight gradients on
+    32 x 32 x 16 matrix tiles (16 features x 64 outputs per wave and 4-point steps, or 8 features and 8-point steps; no
+    second register set: every 512 points the accumulators go to the chunk's partial in memory, by atomic adds after
+    the first time); with PDEKAN_DISABLE_F16_WIDE=1 the 16 x 16 x 32 kernel runs (8 or 4 features per wave).  Same
+    gradients to fp32 reassociation, every other output bit for bit (only the weight gradients change kernel); many
+    chunks, chunks of several flushes, a ragged last chunk, several feature and output blocks, nearly equally spaced
+    knot rows."""
+    lay = _layer(I, O_, G, knots, I + O_ + 1)
     xj, gy = _jets(N, I, O_, N + 1)
     a = _run(lay, xj, gy)
     monkeypatch.setenv("PDEKAN_DISABLE_F16_WIDE", "1")
