@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include "kan_math.h"
 #include "kan_launch.h"
+#include <type_traits>
 
 namespace pdekan {
 
@@ -278,22 +279,40 @@ __device__ __forceinline__ void interleave() {
 #endif
 
 // ==========================================================================================================
-// W planes.  CP = columns per feature in the K index (C1 rounded up so that 4 features are whole k-steps of 32:
-// 14 -> 16, 24 -> 24), a stage = 4 features = KS = CP/8 k-steps.
-//   forward (B operand, K = columns):   wplf[O/64][I/4 stages][KS][4 n][2 planes][64 lanes] x 16 bytes,
+// W planes, both scaled by the power of two that brings max |w| under 2^13.
+//   forward (B operand, K = columns): CP = columns per feature in the K index (C1 rounded up so that 4 features are
+//     whole k-steps of 32: 14 -> 16, 24 -> 24), a stage = 4 features = KS = CP/8 k-steps;
+//     wplf[O/64][I/4 stages][KS][4 n][2 planes][64 lanes] x 16 bytes,
 //     lane (r = lane&15, kb = lane>>4) holds output 64*by + 16n + r, columns 32*ks + kstep_col(kb, 0 .. 7) of the stage
-//   input gradients (B operand, K = outputs): wplb[O/64][I/4 stages][2 ks][NB = CP/4 n][2 planes][64 lanes] x 16 bytes,
-//     lane (r, kb) holds column 16n + r of the stage, outputs 64*by + 32*ks + 8*kb .. + 7
-// both scaled by the power of two that brings max |w| under 2^13.
+//   input gradients (B operand, K = outputs): the columns g = f * C1 + c of a PAIR of stages (8 features) in tiles of
+//     16, no padding: the even stage multiplies the first TA tiles (at grid 10 the last of them reaches 8 columns into
+//     the odd stage's first feature), the odd stage the other TB (BwiTiles);
+//     wplb[O/64][I/8 pairs][even: 2 ks x TA n | odd: 2 ks x TB n][2 planes][64 lanes] x 16 bytes,
+//     lane (r, kb) holds column 16 * tile + r of the pair, outputs 64*by + 32*ks + 8*kb .. + 7
 // ==========================================================================================================
-template <int CP>
+template <int C1>
+struct BwiTiles {
+  static_assert((8 * C1) % 16 == 0, "a pair of stages is whole column tiles");
+  static constexpr int TA = (4 * C1 + 15) / 16, TB = (8 * C1) / 16 - TA;     // 14: 4 + 3; 24: 6 + 6
+  static constexpr int RING = TA * 16;                     // column slots of a parked gE tile: column g sits at g % RING
+  static constexpr int OFFB = 4 * C1;                      // first column of the odd stage
+  static constexpr bool WRAP = OFFB % RING != 0;           // the odd stage's columns start inside the even stage's last tile
+  static constexpr int NRP = 2 * (TA + TB);                // regions (k-step, column tile) per pair
+  static constexpr int kPairVecs = NRP * 2 * 64;           // u32x4 per pair of stages
+  // the B tiles come through a ring of 4 registers sets: where in the ring the stages of two pairs start
+  static constexpr int PH1 = (2 * TA) % 4, PH2 = NRP % 4, PH3 = (NRP + 2 * TA) % 4;
+  static_assert((2 * NRP) % 4 == 0, "two pairs bring the ring back to where it started");
+};
+
+template <int C1>
 __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsigned* __restrict__ wmax,
-                                      u32x4* __restrict__ wplf, u32x4* __restrict__ wplb, int I, int O, int C1) {
-  constexpr int KS = CP / 8, NB = CP / 4;
+                                      u32x4* __restrict__ wplf, u32x4* __restrict__ wplb, int I, int O) {
+  constexpr int CP = (C1 + 7) / 8 * 8, KS = CP / 8;
+  using T = BwiTiles<C1>;
   const float sw = pow2_scale(__uint_as_float(wmax[0]));
-  const int nst = I / 4;
+  const int nst = I / 4, npair = I / 8;
   const int total_f = (O / 64) * nst * KS * 4 * 64;
-  const int total_b = (O / 64) * nst * 2 * NB * 64;
+  const int total_b = (O / 64) * npair * T::NRP * 64;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total_f + total_b; t += gridDim.x * blockDim.x) {
     float v[8];
     u32x4* dst;
@@ -310,16 +329,19 @@ __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsign
       dst = wplf + ((((size_t)(by * nst + st) * KS + ks) * 4 + n) * 2) * 64 + lane;
     } else {
       const int u = t - total_f;
-      const int lane = u & 63, n = (u >> 6) % NB;
-      const int ks = ((u >> 6) / NB) & 1, st = ((u >> 6) / (NB * 2)) % nst, by = (u >> 6) / (NB * 2 * nst);
-      const int k = n * 16 + (lane & 15), kb = lane >> 4;
-      const int f = st * 4 + k / CP, c = k % CP;
+      const int lane = u & 63, q = (u >> 6) % T::NRP;
+      const int pr = ((u >> 6) / T::NRP) % npair, by = (u >> 6) / (T::NRP * npair);
+      const bool odd = q >= 2 * T::TA;
+      const int q2 = odd ? q - 2 * T::TA : q, nb = odd ? T::TB : T::TA;
+      const int ks = q2 / nb, tile = (odd ? T::TA : 0) + q2 % nb;
+      const int g = tile * 16 + (lane & 15), kb = lane >> 4;
+      const int f = pr * 8 + g / C1, c = g % C1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int o = by * 64 + ks * 32 + kb * 8 + e;
-        v[e] = (c < C1) ? wp[((size_t)o * I + f) * C1 + c] * sw : 0.0f;
+        v[e] = wp[((size_t)o * I + f) * C1 + c] * sw;
       }
-      dst = wplb + ((((size_t)(by * nst + st) * 2 + ks) * NB + n) * 2) * 64 + lane;
+      dst = wplb + ((((size_t)(by * npair + pr)) * T::NRP + q) * 2) * 64 + lane;
     }
     unsigned h[4], l[4];
 #pragma unroll
@@ -584,24 +606,22 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
 // ==========================================================================================================
 // input-jet gradients.  gE[(p, j)][k] = sum_o gY[(p, j)][o] * W[o][k]: M = (point, jet), K = 64 outputs (2 k-steps),
 // N = 16 columns.  Wave = 16 points; the A operands (the wave's gY rows, cut into planes once) stay in registers,
-// the B operands (W planes) stream from L2 one column tile at a time, two regions ahead.  A stage = 4 features =
-// NB column tiles x 2 k-steps = 2*NB regions of 12 matrix instructions; its 16 x 4*CP tile of gE is parked in
-// LDS, every (point, feature) lane pulls the 4+1 live columns of its pair and applies the chain rule through
+// the B operands (W planes) stream from L2 one column tile at a time, three regions ahead.  A stage = 4 features =
+// TA or TB column tiles (BwiTiles: the 8 * C1 columns of a pair of stages, unpadded) x 2 k-steps = regions of 12
+// matrix instructions; its tile of gE is parked in LDS at column slot g % RING (an even stage's last tile may hold
+// the first columns of the odd stage's first feature: the odd stage leaves those slots alone), every
+// (point, feature) lane pulls the 4+1 live columns of its pair and applies the chain rule through
 // B', B'', B''' and the activation derivatives - during the matrix instructions of the NEXT stage.
 // Layers wider than 64 outputs are walked 64 outputs at a time; each pass adds its share to the gradients the
 // same lane stored at the same address in the pass before (the chain rule is linear in gE).
 // ==========================================================================================================
 template <int C1, int ACT, bool GEN>
 struct BwiF16 {
-  static constexpr int CP = (C1 + 7) / 8 * 8;
-  static constexpr int NB = CP / 4;                        // column tiles of 16 per stage of 4 features
-  static constexpr int NR = 2 * NB;                        // regions (k-step, column tile) per stage
-  static constexpr int ROW = 4 * CP * 4 + 4;               // words per point in the parked gE tile (+4: bank spread)
+  static constexpr int ROW = BwiTiles<C1>::RING * 4 + 4;   // words per point in the parked gE tile (+4: bank spread)
   static constexpr int GROW = 64 * 4 + 4;                  // words per point of the staged raw gY rows
   static constexpr int TILE = 16 * (ROW > GROW ? ROW : GROW);
   static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
   static constexpr int nk = C1 + 3;
-  static constexpr int kStageVecs = 2 * NB * 2 * 64;       // u32x4 per stage of W planes (input-gradient layout)
 };
 
 // basis with the third derivative for the chain rule: the interval is settled by comparisons against the knots,
@@ -652,7 +672,8 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
                      int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
                      unsigned* __restrict__ cot_out) {
   using F = BwiF16<C1, ACT, GEN>;
-  constexpr int NB = F::NB, NR = F::NR, KP = F::KP, nk = F::nk, CP = F::CP, ROW = F::ROW, GROW = F::GROW;
+  using T = BwiTiles<C1>;
+  constexpr int KP = F::KP, nk = F::nk, ROW = F::ROW, GROW = F::GROW;
   constexpr int C = C1 - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -724,15 +745,16 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
           GAl[m][ks] = (u32x4){l[0], l[1], l[2], l[3]};
         }
     }
-    const u32x4* wbase = wpl + (size_t)ob * nst * F::kStageVecs;
-    // region i of a stage: k-step i / NB, column tile i % NB; its B operand sits at wsrc + i * 128 + lane
+    const u32x4* wbase = wpl + (size_t)ob * (nst / 2) * T::kPairVecs;
+    // region i of a stage of NBs column tiles: k-step i / NBs, column tile i % NBs; its B operand sits at
+    // wsrc + i * 128 + lane
     WTile16 Wt[4];
     auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
     fetch_w(Wt[0], wbase);
     fetch_w(Wt[1], wbase + 128);
     fetch_w(Wt[2], wbase + 256);
 
-    f32x4 acc[4][NB];
+    f32x4 acc[4][T::TA];
     // pipeline registers: `cur` = the pair of the stage being multiplied, `prev` = the pair of the stage before with
     // its gE columns.  Before the first stage `prev` is all zeros: its chain rule then rewrites what is already there.
     PairBack prev, cur;
@@ -748,16 +770,18 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
     cur.x = *reinterpret_cast<const f32x4*>(xrow);
     f32x4 xnext = (nst > 1) ? *reinterpret_cast<const f32x4*>(xrow + 64) : cur.x;
 
-    for (int s = 0; s < nst; ++s) {
-      const u32x4* wsrc = wbase + (size_t)s * F::kStageVecs;
-      const u32x4* wnxt = wbase + (size_t)((s + 1 < nst) ? s + 1 : 0) * F::kStageVecs;
+    // one stage: NBs column tiles, B-tile ring starting at slot PH, ODD: the second stage of its pair
+    auto stage = [&](auto nb_c, auto ph_c, auto odd_c, int s, const u32x4* wsrc, const u32x4* wnxt)
+                     __attribute__((always_inline)) {
+      constexpr int NBs = decltype(nb_c)::value, PH = decltype(ph_c)::value, NRs = 2 * NBs;
+      constexpr bool ODD = decltype(odd_c)::value;
       f32x4* odst = orow + (s > 0 ? s - 1 : 0) * 4;
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int ks = i / NB, n = i % NB;
+      for (int i = 0; i < NRs; ++i) {
+        const int ks = i / NBs, n = i % NBs;
         {                                     // B operand three regions ahead (the slot the last region has just left)
           const int t = i + 3;
-          fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
+          fetch_w(Wt[(t + PH) & 3], (t < NRs) ? wsrc + t * 128 : wnxt + (t - NRs) * 128);
         }
         if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
           f32x4 out = chain_rule(prev, dcol, inv);
@@ -774,7 +798,7 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
           eval_pair_d3<ACT, GEN>(kn, nk, fg, cur.x[0], cur.bs, cur.av);
           if (MULTI) old = (ob > 0) ? orow[s * 4] : old;
         }
-        if (i > NB) {                         // the column tile the region before completed: park it (see below)
+        if (i > NBs) {                        // the column tile the region before completed: park it (see below)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
             *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * (n - 1) + r) * 4) = acc[m][n - 1];
@@ -783,38 +807,63 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h),
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].h),
                                                              ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].l), acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].h), acc[m][n], 0, 0, 0);
         if (i == 0) interleave<12, 10>(); else if (i == 1) interleave<12, 8>(); else interleave<12, 2>();
         PDEKAN_REGION_FENCE();
       }
-      // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column 16n + c.  The tiles
-      // before the last one went out during the regions above (the previous stage's columns were read before them)
+      // park the stage's gE tile: lane (c = r, q = kb) holds the 4 jets of point 4m + q, column slot 16n + c.  The
+      // tiles before the last one went out during the regions above (the previous stage's columns were read before them)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * (NB - 1) + r) * 4) = acc[m][NB - 1];
+        *reinterpret_cast<f32x4*>(sD + (4 * m + kb) * ROW + (16 * (NBs - 1) + r) * 4) = acc[m][NBs - 1];
       // the 4 + 1 live columns of this lane's pair; a column outside [0, C) reads the base column's slot and is
       // zeroed by a select (no branch)
-      const float* drow = sD + p_local * ROW + (f_local * CP) * 4;
+      const float* drow = sD + p_local * ROW;
+      const int g0 = (ODD ? T::OFFB : 0) + f_local * C1;
+      auto slot_of = [&](int c) { return T::WRAP ? (g0 + c) % T::RING : f_local * C1 + c; };
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int c = cur.bs.c0 + m;
         const bool ok = (c >= 0) & (c < C);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(drow + (ok ? c : C) * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(drow + slot_of(ok ? c : C) * 4);
         dcol[m] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      dcol[4] = *reinterpret_cast<const f32x4*>(drow + C * 4);
+      dcol[4] = *reinterpret_cast<const f32x4*>(drow + slot_of(C) * 4);
       prev = cur;
       cur.x = xnext;
       xnext = *reinterpret_cast<const f32x4*>(xrow + (size_t)((s + 2 < nst) ? s + 2 : 0) * 64);
+    };
+    using std::integral_constant;
+    if constexpr (T::TA == T::TB && T::PH1 == 0 && T::PH2 == 0 && T::OFFB % T::RING == 0) {
+      // every stage is whole tiles of its own and leaves the ring where it found it: one stage body
+      for (int s = 0; s < nst; ++s) {
+        const u32x4* pA = wbase + (size_t)s * (T::kPairVecs / 2);
+        stage(integral_constant<int, T::TA>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}, s, pA,
+              (s + 1 < nst) ? pA + T::kPairVecs / 2 : wbase);
+      }
+    } else
+    for (int s = 0; s < nst; s += 4) {          // two pairs of stages (nst is even)
+      const bool more = s + 2 < nst;
+      const u32x4* pA = wbase + (size_t)(s >> 1) * T::kPairVecs;
+      const u32x4* pB = pA + 2 * T::TA * 128;
+      const u32x4* pC = more ? pA + T::kPairVecs : wbase;            // past the end: any valid planes, never multiplied
+      stage(integral_constant<int, T::TA>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}, s, pA, pB);
+      stage(integral_constant<int, T::TB>{}, integral_constant<int, T::PH1>{}, integral_constant<bool, true>{}, s + 1, pB, pC);
+      if (more) {
+        const u32x4* pD = pC + 2 * T::TA * 128;
+        const u32x4* pE = (s + 4 < nst) ? pC + T::kPairVecs : wbase;
+        stage(integral_constant<int, T::TA>{}, integral_constant<int, T::PH2>{}, integral_constant<bool, false>{}, s + 2, pC, pD);
+        stage(integral_constant<int, T::TB>{}, integral_constant<int, T::PH3>{}, integral_constant<bool, true>{}, s + 3, pD, pE);
+      }
     }
     {                                           // chain rule of the last stage
       f32x4 out = chain_rule(prev, dcol, inv);
@@ -1845,15 +1894,11 @@ fwd12_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, co
 // chain rule during the matrix instructions of the next stage (lanes 32..63 repeat lanes 0..31).
 template <int C1, int ACT, bool GEN>
 struct Bwi12 {
-  static constexpr int CP = (C1 + 7) / 8 * 8;
-  static constexpr int NB = CP / 4;
-  static constexpr int NR = 2 * NB;
-  static constexpr int ROW = 4 * CP * 12 + 4;              // words per point in the parked gE tile (+4: bank spread)
+  static constexpr int ROW = BwiTiles<C1>::RING * 12 + 4;  // words per point in the parked gE tile (+4: bank spread)
   static constexpr int GROW = 64 * 12 + 4;                 // words per point of the staged raw gY rows
   static constexpr int TILE = 8 * (ROW > GROW ? ROW : GROW);
   static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
   static constexpr int nk = C1 + 3;
-  static constexpr int kStageVecs = 2 * NB * 2 * 64;
 };
 
 struct PairBack12 { Basis bs; Act av; f32x4 x[3]; };
@@ -1917,7 +1962,8 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
                        const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
                        int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax) {
   using F = Bwi12<C1, ACT, GEN>;
-  constexpr int NB = F::NB, NR = F::NR, KP = F::KP, nk = F::nk, CP = F::CP, ROW = F::ROW, GROW = F::GROW;
+  using T = BwiTiles<C1>;
+  constexpr int KP = F::KP, nk = F::nk, ROW = F::ROW, GROW = F::GROW;
   constexpr int C = C1 - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1996,14 +2042,14 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
           GAl[mt][ks] = (u32x4){l[0], l[1], l[2], l[3]};
         }
     }
-    const u32x4* wbase = wpl + (size_t)ob * nst * F::kStageVecs;
+    const u32x4* wbase = wpl + (size_t)ob * (nst / 2) * T::kPairVecs;
     WTile16 Wt[4];
     auto fetch_w = [&](WTile16& w, const u32x4* src) { w.h = src[lane]; w.l = src[64 + lane]; };
     fetch_w(Wt[0], wbase);
     fetch_w(Wt[1], wbase + 128);
     fetch_w(Wt[2], wbase + 256);
 
-    f32x4 acc[6][NB];
+    f32x4 acc[6][T::TA];
     PairBack12 prev, cur;
     f32x4 dcol[5][3];
     f32x4 old[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -2026,16 +2072,18 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
       xnext[g] = *reinterpret_cast<const f32x4*>(xrow + (nst > 1 ? kStageBytes : 0) + 16 * g);
     }
 
-    for (int s = 0; s < nst; ++s) {
-      const u32x4* wsrc = wbase + (size_t)s * F::kStageVecs;
-      const u32x4* wnxt = wbase + (size_t)((s + 1 < nst) ? s + 1 : 0) * F::kStageVecs;
+    // one stage: NBs column tiles, B-tile ring starting at slot PH, ODD: the second stage of its pair
+    auto stage = [&](auto nb_c, auto ph_c, auto odd_c, int s, const u32x4* wsrc, const u32x4* wnxt)
+                     __attribute__((always_inline)) {
+      constexpr int NBs = decltype(nb_c)::value, PH = decltype(ph_c)::value, NRs = 2 * NBs;
+      constexpr bool ODD = decltype(odd_c)::value;
       f32x4* odst = orow + (s > 0 ? s - 1 : 0) * kStageVec;
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int ks = i / NB, n = i % NB;
+      for (int i = 0; i < NRs; ++i) {
+        const int ks = i / NBs, n = i % NBs;
         {
           const int t = i + 3;                // three regions ahead, into the slot the last region left
-          fetch_w(Wt[t & 3], (t < NR) ? wsrc + t * 128 : wnxt + (t - NR) * 128);
+          fetch_w(Wt[(t + PH) & 3], (t < NRs) ? wsrc + t * 128 : wnxt + (t - NRs) * 128);
         }
         if (i == 0) {                         // chain rule of the stage before, on the columns read after its park
           f32x4 out[3];
@@ -2052,7 +2100,7 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
             for (int g = 0; g < 3; ++g) old[g] = orow[s * kStageVec + g];
           }
         }
-        if (i > NB) {                         // the column tile the region before completed: park it (see below)
+        if (i > NBs) {                        // the column tile the region before completed: park it (see below)
 #pragma unroll
           for (int m = 0; m < 6; ++m)
             *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * (n - 1) + r) * 12 + 4 * (m >> 1)) = acc[m][n - 1];
@@ -2061,42 +2109,68 @@ bwd_input12_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy
 #pragma unroll
         for (int m = 0; m < 6; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAl[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h),
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].h),
                                                              ks == 0 ? zero4 : acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 6; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].l), acc[m][n], 0, 0, 0);
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].l), acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 6; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, GAh[m][ks]),
-                                                             __builtin_bit_cast(f16x8, Wt[i & 3].h), acc[m][n], 0, 0, 0);
+                                                             __builtin_bit_cast(f16x8, Wt[(i + PH) & 3].h), acc[m][n], 0, 0, 0);
         if (i == 0) interleave<18, 14>(); else if (i == 1) interleave<18, 9>(); else interleave<18, 2>();
         PDEKAN_REGION_FENCE();
       }
-      // park the stage's gE tile: lane (c = r, q = kb) holds slots 4g .. 4g+3 of point 4pq + q, column 16n + c
+      // park the stage's gE tile: lane (c = r, q = kb) holds slots 4g .. 4g+3 of point 4pq + q, column slot 16n + c
       // (the tiles before the last one went out during the regions above)
 #pragma unroll
       for (int m = 0; m < 6; ++m)
-        *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * (NB - 1) + r) * 12 + 4 * (m >> 1)) = acc[m][NB - 1];
-      const float* drow = sD + p_local * ROW + (f_local * CP) * 12;
+        *reinterpret_cast<f32x4*>(sD + (4 * (m & 1) + kb) * ROW + (16 * (NBs - 1) + r) * 12 + 4 * (m >> 1)) = acc[m][NBs - 1];
+      const float* drow = sD + p_local * ROW;
+      const int g0 = (ODD ? T::OFFB : 0) + f_local * C1;
+      auto slot_of = [&](int c) { return T::WRAP ? (g0 + c) % T::RING : f_local * C1 + c; };
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int c = cur.bs.c0 + m;
         const bool ok = (c >= 0) & (c < C);
+        const int slot = slot_of(ok ? c : C);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(drow + (ok ? c : C) * 12 + 4 * g);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(drow + slot * 12 + 4 * g);
           dcol[m][g] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
 #pragma unroll
-      for (int g = 0; g < 3; ++g) dcol[4][g] = *reinterpret_cast<const f32x4*>(drow + C * 12 + 4 * g);
+      for (int g = 0; g < 3; ++g) dcol[4][g] = *reinterpret_cast<const f32x4*>(drow + slot_of(C) * 12 + 4 * g);
       prev = cur;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         cur.x[g] = xnext[g];
         xnext[g] = *reinterpret_cast<const f32x4*>(xrow + (size_t)((s + 2 < nst) ? s + 2 : 0) * kStageBytes + 16 * g);
+      }
+    };
+    using std::integral_constant;
+    if constexpr (T::TA == T::TB && T::PH1 == 0 && T::PH2 == 0 && T::OFFB % T::RING == 0) {
+      // every stage is whole tiles of its own and leaves the ring where it found it: one stage body
+      for (int s = 0; s < nst; ++s) {
+        const u32x4* pA = wbase + (size_t)s * (T::kPairVecs / 2);
+        stage(integral_constant<int, T::TA>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}, s, pA,
+              (s + 1 < nst) ? pA + T::kPairVecs / 2 : wbase);
+      }
+    } else
+    for (int s = 0; s < nst; s += 4) {          // two pairs of stages (nst is even)
+      const bool more = s + 2 < nst;
+      const u32x4* pA = wbase + (size_t)(s >> 1) * T::kPairVecs;
+      const u32x4* pB = pA + 2 * T::TA * 128;
+      const u32x4* pC = more ? pA + T::kPairVecs : wbase;            // past the end: any valid planes, never multiplied
+      stage(integral_constant<int, T::TA>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}, s, pA, pB);
+      stage(integral_constant<int, T::TB>{}, integral_constant<int, T::PH1>{}, integral_constant<bool, true>{}, s + 1, pB, pC);
+      if (more) {
+        const u32x4* pD = pC + 2 * T::TA * 128;
+        const u32x4* pE = (s + 4 < nst) ? pC + T::kPairVecs : wbase;
+        stage(integral_constant<int, T::TA>{}, integral_constant<int, T::PH2>{}, integral_constant<bool, false>{}, s + 2, pC, pD);
+        stage(integral_constant<int, T::TB>{}, integral_constant<int, T::PH3>{}, integral_constant<bool, true>{}, s + 3, pD, pE);
       }
     }
     {                                           // chain rule of the last stage
@@ -2405,11 +2479,12 @@ void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* 
   u32x4* f = reinterpret_cast<u32x4*>(wpl);
   u32x4* b = reinterpret_cast<u32x4*>(wpl + f16_wplane_floats(L) / 2);
   const int cp = cp_of(L);
-  const int total = (L.O / 64) * (L.I / 4) * ((cp / 8) * 4 + 2 * (cp / 4)) * 64;
+  const int nrp = (L.G == 10) ? BwiTiles<14>::NRP : BwiTiles<24>::NRP;
+  const int total = (L.O / 64) * ((L.I / 4) * (cp / 8) * 4 + (L.I / 8) * nrp) * 64;
   int blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (cp == 16) pack_wplanes16_kernel<16><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O, L.C1());
-  else pack_wplanes16_kernel<24><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O, L.C1());
+  if (L.G == 10) pack_wplanes16_kernel<14><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  else pack_wplanes16_kernel<24><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
 }
 
 template <typename Kern>
