@@ -10,6 +10,7 @@
 //                    c = C1-1 -> base_weight
 //     wt[I*C1][O]  : the transpose, k = i*C1 + c
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kan_math.h"
 #include "kan_launch.h"
 #include "kan_wave.h"
@@ -435,6 +436,283 @@ bwd_weight_generic_kernel(const float* __restrict__ a, const float* __restrict__
     }
   }
 }
+
+// ==========================================================================
+// First layer of a model that carries many jets (the 5-asset basket: inputs S_1..S_5, t; D = 6 directions, D2 = 5
+// second derivatives, 12 floats per value).  The layer's input jets are seeds - the value, 1 in the input's own
+// direction, zeros elsewhere - so with phi_io the edge function of (input i, output o)
+//   y_0 = sum_i phi_io(x_i),   y_{1+i} = phi_io'(x_i),   y_{1+D+i} = phi_io''(x_i)  (i < D2):
+// 85 multiply-adds per 48 bytes of output instead of the 32 per input and jet-general edge of the kernels above;
+// what is left is writing (forward) and reading (weight gradients) N x O x J floats once.
+//   * a wave takes kSeedBatch points at a time: lane = (point, input) evaluates the 4 live bases, the activation and
+//     their derivatives once and leaves them in the wave's LDS area (no block barrier in the loop);
+//   * then lane = output: the records are broadcast reads, and the pair's interval - wave-uniform - names the 4 + 1
+//     weights (forward: an LDS table) or running sums (weight gradients: registers, picked by a jump) it touches;
+//   * weight gradients: the same walk with gY read instead of y written; lane o keeps the I x C1 sums of its
+//     output in registers and adds A0 B + A1 B' + A2 B'' into the 4 + 1 of them the pair's interval names (a jump on
+//     the wave-uniform interval; sums kept in an LDS table cost 2x as read-add-write and 10x as LDS float atomics);
+//     the sums go out as the chunk's partial part[chunk][O][I][C1].
+// ==========================================================================
+constexpr int kSeedBatch = 8;                 // points per wave and batch
+constexpr int kSeedRec = 16;                  // floats per evaluated (point, input): b[4], d1[4], d2[4], f0, f1, f2, c0
+
+// lane = (point, input) of the batch at P0 -> record in stg; jets_out: where the seed jets are left, or nullptr
+template <int D, int D2>
+__device__ __forceinline__ void seeded_eval_batch(float* stg, const float* sK, int nk, int act, float xv, int lane,
+                                                  bool eval_lane, bool live, float* jets_out) {
+  constexpr int J = 1 + D + D2, I = D;
+  if (!eval_lane) return;
+  const int ei = lane % I;
+  Basis bs;
+  eval_basis_row<false>(sK + ei * (nk + 1), nk, xv, bs);
+  const Act av = eval_act(act, xv);
+  float4* e = reinterpret_cast<float4*>(stg + lane * kSeedRec);
+  e[0] = make_float4(bs.b[0], bs.b[1], bs.b[2], bs.b[3]);
+  e[1] = make_float4(bs.d1[0], bs.d1[1], bs.d1[2], bs.d1[3]);
+  e[2] = make_float4(bs.d2[0], bs.d2[1], bs.d2[2], bs.d2[3]);
+  e[3] = make_float4(av.f0, av.f1, av.f2, __int_as_float(bs.c0));
+  if (jets_out && live) {
+    float jet[J];
+    jet[0] = xv;
+#pragma unroll
+    for (int d = 0; d < D; ++d) jet[1 + d] = (d == ei) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int d = 0; d < D2; ++d) jet[1 + D + d] = 0.0f;
+    if constexpr (J % 4 == 0) {
+#pragma unroll
+      for (int q = 0; q < J / 4; ++q)
+        reinterpret_cast<float4*>(jets_out)[q] = make_float4(jet[4 * q], jet[4 * q + 1], jet[4 * q + 2], jet[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < J; ++j) jets_out[j] = jet[j];
+    }
+  }
+}
+
+#define PDEKAN_SEED_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Block = 4 waves, each on its own stream of point batches and all the layer's outputs (64 at a time); the layer's
+// transposed weights wt[I*C1][O] sit in LDS: the weights of column c0 + m are consecutive over the lanes, the
+// interval is wave-uniform (scalar branch).  A point's 64 jets of a group go out through the wave's LDS tile as
+// 64 * J contiguous floats: every store instruction writes 1 KiB of whole lines (a lane's own jet would be J floats
+// at a stride of J).  (With the weights in registers, picked by a jump like the sums of the weight-gradient kernel,
+// the kernel took 256 + 132 registers and ran at one wave per SIMD: 14 ms against 8 at the 5-asset model's size.)
+constexpr int kSeedOutMax = 4;                // 64-output groups per wave
+
+template <int D, int D2>
+__global__ void __launch_bounds__(256)
+fwd_seeded_kernel(const float* __restrict__ x, int64_t sn, int64_t sd, const float* __restrict__ grid,
+                  const float* __restrict__ ginfo, const float* __restrict__ wt, float* __restrict__ y,
+                  float* __restrict__ a_out, int64_t N, int O, int G, int act, unsigned* __restrict__ amax_out) {
+  constexpr int J = 1 + D + D2, I = D;
+  static_assert(kSeedBatch * I <= 64 && J % 4 == 0, "one (point, input) per lane; whole 16-byte pieces of a jet");
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  const int krow = (I * (nk + 1) + 3) & ~3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sW = reinterpret_cast<float*>(smem);                // [I*C1][O]
+  float* sK = sW + I * C1 * O;                               // [I][nk+1]
+  float* sE = sK + krow;                                     // [4 waves][kSeedBatch*I][kSeedRec]
+  float* sY = sE + 4 * kSeedBatch * I * kSeedRec;            // [4 waves][64 outputs][J]: one point's jets on their way out
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int t = tid; t < I * C1 * O / 4; t += 256) reinterpret_cast<float4*>(sW)[t] = reinterpret_cast<const float4*>(wt)[t];
+  load_knots_to_lds(sK, grid, ginfo, 0, I, I, nk);
+  __syncthreads();
+
+  float* stg = sE + wave * (kSeedBatch * I * kSeedRec);
+  float4* ytile = reinterpret_cast<float4*>(sY + wave * (64 * J));
+  const int ept = lane / I, ei = lane % I, ngrp = O >> 6;
+  const bool eval_lane = lane < kSeedBatch * I;
+  const int64_t nbatch = (N + kSeedBatch - 1) / kSeedBatch;
+  float amax[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) amax[j] = 0.0f;
+  auto fetch_x = [&](int64_t b) {             // this lane's input value of batch b (past the end: any valid point)
+    const int64_t P0 = b * kSeedBatch;
+    const int64_t p = (P0 + ept < N) ? P0 + ept : N - 1;
+    return eval_lane ? x[p * sn + ei * sd] : 0.0f;
+  };
+  const int64_t bstride = (int64_t)gridDim.x * 4;
+  int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  float xnext = (b < nbatch) ? fetch_x(b) : 0.0f;
+  for (; b < nbatch; b += bstride) {
+    const int64_t P0 = b * kSeedBatch;
+    const int nlive = (int)((N - P0 < kSeedBatch) ? (N - P0) : kSeedBatch);
+    const float xv = xnext;
+    if (b + bstride < nbatch) xnext = fetch_x(b + bstride);
+    seeded_eval_batch<D, D2>(stg, sK, nk, act, xv, lane, eval_lane, ept < nlive,
+                             (a_out && eval_lane) ? a_out + ((P0 + (ept < nlive ? ept : 0)) * I + ei) * J : nullptr);
+    PDEKAN_SEED_WAVE_SYNC();
+    for (int pt = 0; pt < nlive; ++pt) {
+      float acc[kSeedOutMax][J];
+#pragma unroll
+      for (int g = 0; g < kSeedOutMax; ++g)
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[g][j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < I; ++i) {
+        const float4* e = reinterpret_cast<const float4*>(stg + (pt * I + i) * kSeedRec);
+        const float4 vb = e[0], v1 = e[1], v2 = e[2], vf = e[3];
+        const int c0 = __builtin_amdgcn_readfirstlane(__float_as_int(vf.w));
+        const float bb[4] = {vb.x, vb.y, vb.z, vb.w}, b1[4] = {v1.x, v1.y, v1.z, v1.w}, b2[4] = {v2.x, v2.y, v2.z, v2.w};
+        const float* wrow = sW + (size_t)(i * C1) * O + lane;
+#pragma unroll
+        for (int g = 0; g < kSeedOutMax; ++g) {
+          if (g < ngrp) {
+            const float* wcol = wrow + 64 * g;
+            const float wbase = wcol[(size_t)C * O];
+            float p0 = wbase * vf.x, p1 = wbase * vf.y, p2 = wbase * vf.z;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int c = c0 + m;
+              if (c >= 0 && c < C) {
+                const float w = wcol[(size_t)c * O];
+                p0 += w * bb[m]; p1 += w * b1[m]; p2 += w * b2[m];
+              }
+            }
+            acc[g][0] += p0;
+            acc[g][1 + i] = p1;
+            if (i < D2) acc[g][1 + D + i] = p2;
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kSeedOutMax; ++g) {
+        if (g < ngrp) {
+#pragma unroll
+          for (int q = 0; q < J / 4; ++q)
+            ytile[lane * (J / 4) + q] = make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+#pragma unroll
+          for (int j = 0; j < J; ++j) absmax_into(amax[j], acc[g][j]);
+          PDEKAN_SEED_WAVE_SYNC();
+          float4* dst = reinterpret_cast<float4*>(y + ((P0 + pt) * O + 64 * g) * J);
+#pragma unroll
+          for (int q = 0; q < J / 4; ++q) dst[64 * q + lane] = ytile[64 * q + lane];
+          PDEKAN_SEED_WAVE_SYNC();
+        }
+      }
+    }
+    PDEKAN_SEED_WAVE_SYNC();                   // the records are free for the next batch
+  }
+  if (amax_out) publish_slot_absmax<J>(amax, amax_out);
+}
+
+struct SeedRec { float4 b, d1, d2, f; };      // the record of one evaluated (point, input), as read back from LDS
+__device__ __forceinline__ SeedRec read_seed_rec(const float* stg, int pair) {
+  const float4* e = reinterpret_cast<const float4*>(stg + pair * kSeedRec);
+  return {e[0], e[1], e[2], e[3]};
+}
+
+// the 4 live columns c0 .. c0+3 of one (point, input) into the lane's sums of that input: c0 is wave-uniform (a
+// scalar register), so this is a few scalar branches and then adds into registers named at compile time.  Only the
+// adds sit in the cases: the kernel below unrolls 8 points x 6 inputs of them, and with the multiply-adds inside
+// its loop was 240 KB of code that ran at the speed of the instruction cache's misses.
+#define PDEKAN_SEED_CASE(K)                                                                      \
+  case K: {                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                \
+      if (K + m >= 0 && K + m < C) acc[(K + m) < 0 ? 0 : ((K + m) < C ? (K + m) : 0)] += v[m];   \
+  } break;
+template <int C>
+__device__ __forceinline__ void seeded_add_columns(float (&acc)[C + 1], int c0, const float (&v)[4]) {
+  static_assert(C <= 23, "cases up to grid size 20");
+  switch (c0) {
+    PDEKAN_SEED_CASE(-3) PDEKAN_SEED_CASE(-2) PDEKAN_SEED_CASE(-1) PDEKAN_SEED_CASE(0) PDEKAN_SEED_CASE(1)
+    PDEKAN_SEED_CASE(2) PDEKAN_SEED_CASE(3) PDEKAN_SEED_CASE(4) PDEKAN_SEED_CASE(5) PDEKAN_SEED_CASE(6)
+    PDEKAN_SEED_CASE(7) PDEKAN_SEED_CASE(8) PDEKAN_SEED_CASE(9) PDEKAN_SEED_CASE(10) PDEKAN_SEED_CASE(11)
+    PDEKAN_SEED_CASE(12) PDEKAN_SEED_CASE(13) PDEKAN_SEED_CASE(14) PDEKAN_SEED_CASE(15) PDEKAN_SEED_CASE(16)
+    PDEKAN_SEED_CASE(17) PDEKAN_SEED_CASE(18) PDEKAN_SEED_CASE(19) PDEKAN_SEED_CASE(20) PDEKAN_SEED_CASE(21)
+    PDEKAN_SEED_CASE(22)
+    default: break;
+  }
+}
+#undef PDEKAN_SEED_CASE
+
+// a: the seed jets the forward left ([N][I][J]; only the values are read), gy: [N][O][J].  Block = O / 64 waves on
+// one chunk of points (blockIdx.x), wave w on outputs 64w .. 64w+63; chunk_pts is a multiple of kSeedBatch.  The gY
+// jets of a point are fetched four points ahead, into the registers the point four before it has just left.
+template <int D, int D2, int G>
+__global__ void __launch_bounds__(256, G <= 10 ? 2 : 1)
+bwd_weight_seeded_kernel(const float* __restrict__ a, const float* __restrict__ gy, const float* __restrict__ grid,
+                         const float* __restrict__ ginfo, float* __restrict__ part, int64_t N, int O, int act,
+                         int64_t chunk_pts) {
+  constexpr int J = 1 + D + D2, I = D, Q = J / 4;
+  static_assert(kSeedBatch * I <= 64 && J % 4 == 0, "one (point, input) per lane; whole 16-byte pieces of a jet");
+  constexpr int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1;
+  constexpr int krow = (I * (nk + 1) + 3) & ~3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sK = reinterpret_cast<float*>(smem);
+  float* sE = sK + krow;                                     // [waves][kSeedBatch*I][kSeedRec]
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  load_knots_to_lds(sK, grid, ginfo, 0, I, I, nk);
+  __syncthreads();
+
+  float* stg = sE + wave * (kSeedBatch * I * kSeedRec);
+  const int ept = lane / I, ei = lane % I, o = wave * 64 + lane;
+  const bool eval_lane = lane < kSeedBatch * I;
+  const int64_t pbeg = (int64_t)blockIdx.x * chunk_pts;
+  const int64_t pend = (pbeg + chunk_pts < N) ? pbeg + chunk_pts : N;
+  float acc[I][C1];                                          // sums of this lane's output: [input][column]
+#pragma unroll
+  for (int i = 0; i < I; ++i)
+#pragma unroll
+    for (int c = 0; c < C1; ++c) acc[i][c] = 0.0f;
+
+  if (pbeg < pend) {
+    auto fetch_x = [&](int64_t P0) {          // (past the end of the chunk: any valid point)
+      const int64_t pe = (P0 + ept < pend) ? P0 + ept : pend - 1;
+      return eval_lane ? a[(pe * I + ei) * J] : 0.0f;
+    };
+    auto fetch_g = [&](int64_t p, float4 (&g)[Q]) {
+      const float4* src = reinterpret_cast<const float4*>(gy + (((p < pend) ? p : pend - 1) * O + o) * J);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) g[q] = src[q];
+    };
+    constexpr int kRing = 4;                  // points whose gY jets are in registers or on their way
+    float4 g[kRing][Q];
+#pragma unroll
+    for (int pt = 0; pt < kRing; ++pt) fetch_g(pbeg + pt, g[pt]);
+    float xv = fetch_x(pbeg);
+    for (int64_t P0 = pbeg; P0 < pend; P0 += kSeedBatch) {
+      const int nlive = (int)((pend - P0 < kSeedBatch) ? (pend - P0) : kSeedBatch);
+      const float xnext = fetch_x(P0 + kSeedBatch < pend ? P0 + kSeedBatch : pbeg);
+      seeded_eval_batch<D, D2>(stg, sK, nk, act, xv, lane, eval_lane, false, nullptr);
+      PDEKAN_SEED_WAVE_SYNC();
+      for (int h = 0; h < kSeedBatch / kRing; ++h) {         // (not unrolled: the code below is large)
+#pragma unroll
+        for (int r = 0; r < kRing; ++r) {
+          const int pt = h * kRing + r;
+          if (pt < nlive) {
+            float gj[J];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { gj[4 * q] = g[r][q].x; gj[4 * q + 1] = g[r][q].y; gj[4 * q + 2] = g[r][q].z; gj[4 * q + 3] = g[r][q].w; }
+            SeedRec rec = read_seed_rec(stg, pt * I);
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+              const float4 vb = rec.b, v1 = rec.d1, v2 = rec.d2, vf = rec.f;
+              if (i + 1 < I) rec = read_seed_rec(stg, pt * I + i + 1);   // (ahead of the branches below)
+              const int c0 = __builtin_amdgcn_readfirstlane(__float_as_int(vf.w));
+              const float A0 = gj[0], A1 = gj[1 + i], A2 = (i < D2) ? gj[1 + D + (i < D2 ? i : 0)] : 0.0f;
+              acc[i][C] += A0 * vf.x + A1 * vf.y + A2 * vf.z;
+              const float v[4] = {A0 * vb.x + A1 * v1.x + A2 * v2.x, A0 * vb.y + A1 * v1.y + A2 * v2.y,
+                                  A0 * vb.z + A1 * v1.z + A2 * v2.z, A0 * vb.w + A1 * v1.w + A2 * v2.w};
+              seeded_add_columns<C>(acc[i], c0, v);
+            }
+          }
+          fetch_g(P0 + pt + kRing, g[r]);                    // the same slot, four points on
+        }
+      }
+      PDEKAN_SEED_WAVE_SYNC();
+      xv = xnext;
+    }
+  }
+  // part[chunk][o][i][c]: the words of this lane's own output
+  float* dst = part + ((size_t)blockIdx.x * O + o) * I * C1;
+#pragma unroll
+  for (int i = 0; i < I; ++i)
+#pragma unroll
+    for (int c = 0; c < C1; ++c) dst[i * C1 + c] = acc[i][c];
+}
+#undef PDEKAN_SEED_WAVE_SYNC
 
 // --------------------------------------------------------------------------
 // sum part[chunk][total] over the chunks into out[total]: a block takes 64
@@ -1092,6 +1370,53 @@ static void residual_t(const float* x, int64_t sn, int64_t sd, const float* vjet
                                                      loss_part, N);
 }
 
+// first layers the seeded kernels take (fwd_seeded_kernel, bwd_weight_seeded_kernel): as many inputs as directions,
+// so that the seeds make input i direction i; 64, 128 or 256 outputs (the groups of 64 divide a block's 4 waves)
+static size_t fwd_seeded_lds_bytes(const LayerView& L) {
+  const int krow = (L.I * (L.nk() + 1) + 3) & ~3;
+  return ((size_t)L.I * L.C1() * L.O + krow + 4 * ((size_t)kSeedBatch * L.I * kSeedRec + 64 * 12)) * 4;
+}
+
+bool seeded_first_layer(int D, int D2, const LayerView& L) {
+  if (D != 6 || D2 != 5 || L.I != D || L.O % 64 != 0 || L.O > 256 || L.O == 192) return false;
+  if (L.G != 5 && L.G != 10 && L.G != 20) return false;      // (the kernels are built per grid size)
+  const char* off = getenv("PDEKAN_DISABLE_SEEDED_FIRST");   // A/B switch for tests and profiling
+  if (off && off[0] == '1') return false;
+  return fwd_seeded_lds_bytes(L) <= 128 * 1024;
+}
+
+static void fwd_seeded_launch(const LayerView& L, const float* wt, float* y, int64_t N, hipStream_t st,
+                              unsigned* amax_out, const SeedSrc& seed) {
+  auto k = fwd_seeded_kernel<6, 5>;
+  const size_t lds = fwd_seeded_lds_bytes(L);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+  const int64_t nbatch = (N + kSeedBatch - 1) / kSeedBatch;
+  int64_t blocks = (nbatch + 3) / 4;
+  const int64_t resident = 256 * (lds <= 72 * 1024 ? 2 : 1);    // blocks the chip holds at once
+  if (blocks > resident) blocks = resident;
+  k<<<(unsigned)blocks, 256, lds, st>>>(seed.x, seed.sn, seed.sd, L.grid, L.ginfo, wt, y, seed.a_out, N, L.O, L.G, L.act,
+                                        amax_out);
+}
+
+template <int G>
+static void bwd_weight_seeded_launch_g(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                                       int64_t N, hipStream_t st) {
+  const int waves = L.O / 64;
+  const int krow = (L.I * (L.nk() + 1) + 3) & ~3;
+  const size_t lds = ((size_t)krow + (size_t)waves * kSeedBatch * L.I * kSeedRec) * 4;
+  int64_t chunk = (N + nchunks - 1) / nchunks;
+  chunk = (chunk + kSeedBatch - 1) / kSeedBatch * kSeedBatch;
+  bwd_weight_seeded_kernel<6, 5, G><<<(unsigned)nchunks, 64 * waves, lds, st>>>(a, gy, L.grid, L.ginfo, part, N, L.O, L.act,
+                                                                               chunk);
+}
+
+static void bwd_weight_seeded_launch(const LayerView& L, const float* a, const float* gy, float* part, int nchunks,
+                                     int64_t N, hipStream_t st) {
+  if (L.G == 5) bwd_weight_seeded_launch_g<5>(L, a, gy, part, nchunks, N, st);
+  else if (L.G == 10) bwd_weight_seeded_launch_g<10>(L, a, gy, part, nchunks, N, st);
+  else bwd_weight_seeded_launch_g<20>(L, a, gy, part, nchunks, N, st);
+}
+
 #define PDEKAN_DISPATCH_JET(D_, D2_, CALL)                       \
   if ((D_) == 0 && (D2_) == 0) { CALL(0, 0); }                   \
   else if ((D_) == 2 && (D2_) == 1) { CALL(2, 1); }              \
@@ -1109,6 +1434,10 @@ bool launch_seed_jets(int D, int D2, const float* x, int64_t sn, int64_t sd, flo
 // seed (x != nullptr): only for layers fwd_generic_takes_seed() accepts (one window of input features)
 bool launch_fwd_generic(int D, int D2, const LayerView& L, const float* a, const float* wt, float* y, int64_t N,
                         hipStream_t st, bool skip_near_uniform, unsigned* amax_out, SeedSrc seed) {
+  if (seed.x && !skip_near_uniform && seeded_first_layer(D, D2, L)) {
+    fwd_seeded_launch(L, wt, y, N, st, amax_out, seed);
+    return true;
+  }
 #define CALL(A, B) fwd_t<A, B>(L, a, wt, y, N, st, skip_near_uniform, amax_out, seed)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL
@@ -1131,7 +1460,11 @@ bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a,
 }
 
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
-                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform) {
+                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform, bool seeded_input) {
+  if (seeded_input && !skip_near_uniform && seeded_first_layer(D, D2, L)) {
+    bwd_weight_seeded_launch(L, a, gy, part, nchunks, N, st);
+    return true;
+  }
 #define CALL(A, B) bwd_weight_t<A, B>(L, a, gy, part, nchunks, N, st, skip_near_uniform)
   PDEKAN_DISPATCH_JET(D, D2, CALL)
 #undef CALL

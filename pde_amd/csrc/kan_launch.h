@@ -68,8 +68,12 @@ bool fwd_sparse_takes_seed(const LayerView& L);
 bool launch_bwd_input_generic(int D, int D2, const LayerView& L, const float* a, const float* gy,
                               const float* wp, float* ga, int64_t N, hipStream_t st, bool skip_near_uniform = false);
 int generic_weight_chunks(int64_t N, int I, int O);
+// seeded_input: a holds the seed jets of a model's first layer (value, 1 in the input's own direction, zeros)
 bool launch_bwd_weight_generic(int D, int D2, const LayerView& L, const float* a, const float* gy, float* part,
-                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform = false);
+                               int nchunks, int64_t N, hipStream_t st, bool skip_near_uniform = false,
+                               bool seeded_input = false);
+// first layers of 12-jet models that have kernels of their own behind the two launchers above
+bool seeded_first_layer(int D, int D2, const LayerView& L);
 // sum_buf: packed_floats() floats of scratch, used when nchunks > 1 or with sel
 // sel.ginfo given: the chunks summed are [first_uniform, + n_uniform) when every knot row of the layer is (nearly)
 // equally spaced, else [first_other, + n_other) - settled on the device (nchunks is not used then)

@@ -124,6 +124,10 @@ struct Carver {
 int weight_chunks(int D, int D2, const pdekan::LayerView& L, int64_t n) {
   if (pdekan::mfma_eligible(D, D2, L)) return pdekan::mfma_weight_chunks(n, L);
   if (pdekan::mfma_skinny_weight_eligible(D, D2, L)) return pdekan::mfma_skinny_weight_chunks(n, L);
+  if (pdekan::seeded_first_layer(D, D2, L)) {               // four resident waves per SIMD's worth of chunks
+    const int64_t want = 4096 / (L.O / 64), cap = (n + 127) / 128;
+    return (int)(want < cap ? want : (cap < 1 ? 1 : cap));
+  }
   return pdekan::generic_weight_chunks(n, L.I, L.O);
 }
 
@@ -236,7 +240,7 @@ int run_forward(int D, int D2, const pdekan::LayerView& L, const float* a, const
 
 int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, const float* gy, const float* wp,
                  const float* win, float* ga, float* part, const PdekanLayerGrad* g, int accumulate, int64_t n,
-                 hipStream_t st, int li = 0, const F16Io* h = nullptr) {
+                 hipStream_t st, int li = 0, const F16Io* h = nullptr, bool seeded_input = false) {
   const bool mf = pdekan::mfma_eligible(D, D2, L);
   if (g) {
     if (!g->base_weight || !g->spline_weight || (L.scaler && !g->spline_scaler))
@@ -256,7 +260,7 @@ int run_backward(int D, int D2, const pdekan::LayerView& L, const float* a, cons
       pdekan::launch_bwd_weight_mfma_skinny(L, a, gy, part, nch, n, st);
     } else {
       ProfScope ps(st, "L%d.bwd_weight.stream", li);
-      if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st))
+      if (!pdekan::launch_bwd_weight_generic(D, D2, L, a, gy, part, nch, n, st, false, seeded_input))
         return fail(PDEKAN_ERR_ARG, "jet shape (%d,%d) unsupported", D, D2);
     }
     ProfScope ps(st, "L%d.reduce_unpack", li);
@@ -959,7 +963,7 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
           }
           cot_ready = f16 && io.cot_out != nullptr;
           rc = run_backward(P.D, P.D2, P.L[l], W.act[l], W.g[cur], W.wp[l], W.win[l], gnext, W.part, &grads[l], acc_flag,
-                            m, st, l, f16 ? &io : nullptr);
+                            m, st, l, f16 ? &io : nullptr, l == 0);     // (W.act[0]: the seed jets)
         }
         if (rc) return rc;
         cur ^= 1;

@@ -1,16 +1,18 @@
 // What the fp16 matrix pipe sustains on RANDOM operands (the clock under matrix load is set by power): dense
-// TFLOP/s and in-kernel clock of bare loops of v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16, operands in
+// TFLOP/s and in-kernel clock of bare loops of v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 / the older
+// v_mfma_f32_16x16x16_f16 (half the K per instruction), operands in
 // registers, 1 or 2 waves per SIMD, zero or random data.  hipcc --offload-arch=gfx950 -O3 scripts/ubench_mfma_f16_power.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
 
-template <int SHAPE>   // 0: 32x32x16, 4 accumulators; 1: 16x16x32, 16 accumulators
+template <int SHAPE>   // 0: 32x32x16, 4 accumulators; 1: 16x16x32, 16 accumulators; 2: 16x16x16, 16 accumulators
 __global__ void __launch_bounds__(256) kern(float* out, unsigned long long* clk, int iters, int random) {
   unsigned s = 12345u + threadIdx.x * 7919u + blockIdx.x * 104729u;
   f16x8 a[4], b[4];
@@ -30,9 +32,15 @@ __global__ void __launch_bounds__(256) kern(float* out, unsigned long long* clk,
     if (SHAPE == 0) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) c32[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 3], b[(u >> 2) & 3], c32[u & 3], 0, 0, 0);
-    } else {
+    } else if (SHAPE == 1) {
 #pragma unroll
       for (int u = 0; u < 32; ++u) c16[u & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 3], b[(u >> 2) & 3], c16[u & 15], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 64; ++u)
+        c16[u & 15] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a[u & 3], a[u & 3], 0, 1, 2, 3),
+                                                            __builtin_shufflevector(b[(u >> 2) & 3], b[(u >> 2) & 3], 4, 5, 6, 7),
+                                                            c16[u & 15], 0, 0, 0);
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -64,6 +72,6 @@ int main() {
   float* out; unsigned long long* clk;
   hipMalloc(&out, 512 * 256 * 4); hipMalloc(&clk, 512 * 16);
   for (int w = 1; w <= 2; ++w)
-    for (int r = 0; r <= 1; ++r) { run<0>("32x32x16", w, r, out, clk); run<1>("16x16x32", w, r, out, clk); }
+    for (int r = 0; r <= 1; ++r) { run<0>("32x32x16", w, r, out, clk); run<1>("16x16x32", w, r, out, clk); run<2>("16x16x16", w, r, out, clk); }
   return 0;
 }

@@ -475,3 +475,44 @@ def test_small_model_step_in_two_launches_equals_the_layer_by_layer_step(widths,
     flat_ref = torch.cat([ref["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in KEYS
                           if ref["grads"][l][k] is not None])
     assert max_rel(grad_s.cpu(), flat_ref) <= TOL
+
+
+@pytest.mark.parametrize("widths,N,moved", [([6, 64, 1], 1, False), ([6, 64, 1], 77, True), ([6, 128, 64, 1], 4101, False),
+                                            ([6, 256, 1], 300, False), ([6, 128, 128, 1], 20000, True)])
+def test_first_layer_kernels_of_the_basket_model(widths, N, moved, monkeypatch):
+    """The first layer of a 12-jet model (6 inputs = 6 directions: its input jets are seeds) has a forward and a
+    weight-gradient kernel of its own: 85 multiply-adds per output jet, weights in LDS, weight gradients summed in
+    LDS per chunk.  One point, batches with dead points, 64 to 256 outputs, a first layer whose knots update_grid
+    has moved, a target: same step as with those kernels switched off (PDEKAN_DISABLE_SEEDED_FIRST=1: the streaming
+    kernels), as the fp64 oracle, and bit for bit the same from run to run."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, 10, 41 + N % 5)
+    gen = torch.Generator().manual_seed(N)
+    x = torch.rand(N, 6, generator=gen)
+    target = 0.1 * torch.randn(N, generator=gen)
+    m = m.cuda()
+    if moved:
+        with torch.no_grad():
+            m.layers[0].update_grid(torch.rand(400, 6, generator=gen).cuda() * 1.2 - 0.1)
+    layers64 = O.layers_from_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, dtype=torch.float64)
+    ref = O.pinn_step(x.double(), layers64, "silu", target=target.double())
+
+    def run():
+        step = BlackScholesStep(m)
+        res = torch.empty(N, device="cuda")
+        loss = step(x.cuda(), target=target.cuda(), residual_out=res)
+        return loss.clone(), res, step.flat_grad.clone()
+
+    loss_a, res_a, grad_a = run()
+    loss_a2, res_a2, grad_a2 = run()
+    monkeypatch.setenv("PDEKAN_DISABLE_SEEDED_FIRST", "1")
+    loss_b, res_b, grad_b = run()
+    monkeypatch.delenv("PDEKAN_DISABLE_SEEDED_FIRST")
+    assert torch.equal(loss_a, loss_a2) and torch.equal(res_a, res_a2) and torch.equal(grad_a, grad_a2)
+    assert max_rel(res_a.cpu(), res_b.cpu()) <= 2e-6 and max_rel(grad_a.cpu(), grad_b.cpu()) <= 5e-6
+    assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * abs(loss_b.item())
+    assert not torch.equal(grad_a, grad_b)                  # (the switch does change the kernels)
+    flat_ref = torch.cat([ref["grads"][l][k].flatten() for l in range(len(widths) - 1) for k in KEYS])
+    assert max_rel(res_a.cpu(), ref["res"]) <= TOL
+    assert abs(loss_a.item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    assert max_rel(grad_a.cpu(), flat_ref) <= TOL
