@@ -1660,6 +1660,24 @@ __device__ __forceinline__ void column12(const PairKeep12x& pk, const RowCoefs12
   col[2] = rc.be[2] * b1 + rc.ga[2] * b2;
 }
 
+// the same for the column a half-wave takes when the two halves of a wave, which hold the same pairs, share a pair's
+// columns: step j = 0, 1: live column j (lanes 0..31) or 2 + j (lanes 32..63); j = 2: the base column (upper half: unused)
+__device__ __forceinline__ void column12_half(const PairKeep12x& pk, const RowCoefs12& rc, int j, bool upper, f32x4 (&col)[3]) {
+  float b0, b1, b2;
+  if (j < 2) {
+    b0 = upper ? pk.bs.b[2 + (j & 1)] : pk.bs.b[j & 1];
+    b1 = upper ? pk.bs.d1[2 + (j & 1)] : pk.bs.d1[j & 1];
+    b2 = upper ? pk.bs.d2[2 + (j & 1)] : pk.bs.d2[j & 1];
+  } else {
+    b0 = pk.av.f0; b1 = pk.av.f1; b2 = pk.av.f2;
+  }
+  col[0] = rc.be[0] * b1;
+  col[0][0] = rc.s0 * b0;
+  col[1] = rc.be[1] * b1;
+  col[1][3] += rc.ga[1][3] * b2;
+  col[2] = rc.be[2] * b1 + rc.ga[2] * b2;
+}
+
 __device__ __forceinline__ Planes12 split_col12(const f32x4 (&c)[3]) {
   Planes12 p;
 #pragma unroll
@@ -1700,9 +1718,41 @@ __device__ __forceinline__ void park_pair12(unsigned* base, unsigned* dump, cons
   prev_c0 = c0;
 }
 
+// the park of a half-wave (column12_half): clears the two live columns this half wrote a stage earlier, writes its two
+// live columns and (lower half) the base column; the upper half's third column goes to the dump row
+template <int C1, int PLANE>
+__device__ __forceinline__ void park_pair12_half(unsigned* base, unsigned* dump, const Planes12 (&pp)[3], int c0, int& prev_c0,
+                                                 bool upper) {
+  constexpr int C = C1 - 1;
+  const u32x2 zero = {0u, 0u};
+  const int h2 = upper ? 2 : 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = prev_c0 + h2 + j;
+    unsigned* dst = (c >= 0 && c < C) ? base + c * kRowWords12 : dump;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      *reinterpret_cast<u32x2*>(dst + 16 * g) = zero;
+      *reinterpret_cast<u32x2*>(dst + 16 * g + PLANE) = zero;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = c0 + h2 + j;
+    unsigned* dst = (j == 2) ? (upper ? dump : base + C * kRowWords12) : ((c >= 0 && c < C) ? base + c * kRowWords12 : dump);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      *reinterpret_cast<u32x2*>(dst + 16 * g) = pp[j].h[g];
+      *reinterpret_cast<u32x2*>(dst + 16 * g + PLANE) = pp[j].l[g];
+    }
+  }
+  prev_c0 = c0;
+}
+
 // ---- forward, 12 jets: wave = 8 points x 3 groups = 6 row tiles x 64 outputs (24 accumulator tiles), one wave per
 // SIMD.  Stage = 4 features = KS k-steps x 6 row tiles = 6*KS regions of 12 matrix instructions.  Lanes 32..63
-// repeat the pairs of lanes 0..31 (same values to the same LDS words).  N must be a multiple of 8.
+// hold the pairs of lanes 0..31 again: the two halves share a pair's columns (two live columns + the base column
+// below, the other two live columns above).  N must be a multiple of 8.
 template <int C1, int ACT, bool GEN>
 struct Fwd12 {
   static constexpr int CP = (C1 + 7) / 8 * 8;
@@ -1720,8 +1770,8 @@ struct Fwd12 {
   // pipe idles once it exceeds two instructions):
   //   region 0            basis and activation of the pairs
   //   region 1            row coefficients of the three groups; fetch the input jets of the stage after the next
-  //   regions 1 .. 5      column m = region - 1 of all groups
-  //   regions 2 .. 6      cut column m = region - 2
+  //   regions 1 .. 3      this half-wave's column j = region - 1 of all groups
+  //   regions 2 .. 4      cut column j = region - 2
   //   region NR-2         park the next stage's planes
   template <bool FLIP>
   static __device__ __forceinline__ void stage(f32x4 (&acc)[6][4], WTiles16& Wa, WTiles16& Wb, ATile16& cur, ATile16& nxt,
@@ -1731,10 +1781,11 @@ struct Fwd12 {
                                                const int (&aoff)[KS][2], int lane) {
     static_assert(NR >= 9, "the plan below needs 7 regions before the park");
     const int p_local = lane & 7, f_local = (lane >> 3) & 3;
+    const bool upper = lane >= 32;
     PairKeep12x pk;
     RowCoefs12 rc;
     f32x4 col[3];
-    Planes12 pp[5];
+    Planes12 pp[3];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int ks = i / 6, m = i % 6;
@@ -1742,7 +1793,7 @@ struct Fwd12 {
       WTiles16& Wc = odd ? Wb : Wa;
       WTiles16& Wn = odd ? Wa : Wb;
       if (m < 4) load_w16(Wn, (ks + 1 < KS) ? wsrc + (ks + 1) * kStepVecs : wnext, lane, m);
-      if (i >= 2 && i <= 6) pp[i - 2] = split_col12(col);           // (the column the region before computed)
+      if (i >= 2 && i <= 4) pp[i - 2] = split_col12(col);           // (the column the region before computed)
       if (i == 0) {
         const FeatGrid fg = {knots_next[0], knots_next[nk - 1], fabsf(knots_next[GEN ? nk + 4 : nk])};
         if constexpr (GEN) eval_basis_near_uniform(knots_next, nk, fg.g0, fg.glast, fg.inv_h, xraw[0][0], pk.bs);
@@ -1754,18 +1805,18 @@ struct Fwd12 {
 #pragma unroll
         for (int g = 0; g < 3; ++g) xraw[g] = *reinterpret_cast<const f32x4*>(xnext2 + 16 * g);
       }
-      if (i >= 1 && i <= 5) column12(pk, rc, i - 1, col);
+      if (i >= 1 && i <= 3) column12_half(pk, rc, i - 1, upper, col);
       if (i == NR - 2) {
         __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): retire the reads in flight before the run of writes
         unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
-        park_pair12<C1, PLANE>(base, sE + (ROWS - 1) * kRowWords12 + p_local * 2, pp, pk.bs.c0, prev_c0);
+        park_pair12_half<C1, PLANE>(base, sE + (ROWS - 1) * kRowWords12 + p_local * 2, pp, pk.bs.c0, prev_c0, upper);
       }
       const int t2 = (i + 2) % NR;
       const ATile16 far = read_atile16<PLANE>(sE, aoff[t2 / 6][0], aoff[t2 / 6][1], t2 % 6);
       mfma3x4(acc[m], cur.h, cur.l, Wc.h, Wc.l);
       cur = nxt;
       nxt = far;
-      if (i <= 6) interleave<12, 5>(); else interleave<12, 3>();
+      if (i <= 4) interleave<12, 5>(); else interleave<12, 3>();
       PDEKAN_REGION_FENCE();
     }
   }
