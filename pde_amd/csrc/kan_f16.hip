@@ -190,6 +190,12 @@ constexpr int kRowWords = 40;
 // that the two lane groups that share an LDS access (kb = 0, 1 or 2, 3) read 8 consecutive rows of the tile.
 __host__ __device__ constexpr int kstep_col(int kb, int e) { return 16 * (kb >> 1) + 8 * (e >> 2) + 4 * (kb & 1) + (e & 3); }
 
+// Order of a feature's 16 columns inside a k-step of the 32 x 32 x 16 forward (A operand's transposed reads and packed B operand alike): element
+// e of lane half h is column 8h + 2 (e & 3) + (e >> 2).  The first transposed read of a 32-lane half then takes 4
+// rows of the E tile two apart and the second the 4 rows between them, so the two 16-lane groups of the half - which
+// read different (point, row) blocks of the same rows - land on different banks.
+__host__ __device__ constexpr int wide_col(int h, int e) { return 8 * h + 2 * (e & 3) + (e >> 2); }
+
 // park a pair's planes: clear the columns written one stage earlier, write the live ones
 template <int C1, int PLANE>
 __device__ __forceinline__ void park_pair16(unsigned* base, unsigned* dump, const Planes16 (&pp)[5], int c0, int& prev_c0) {
@@ -304,7 +310,10 @@ struct BwiTiles {
   static_assert((2 * NRP) % 4 == 0, "two pairs bring the ring back to where it started");
 };
 
-template <int C1>
+// WIDE (C1 = 14): the forward image is laid out for fwd12w_f16_kernel instead,
+//   wplf[O/64][I features][2 n][2 planes][64 lanes] x 16 bytes, lane (r = lane&31, h = lane>>5) holds output
+//   64*by + 32n + r, columns wide_col(h, 0 .. 7) of the feature (the same number of bytes)
+template <int C1, bool WIDE>
 __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsigned* __restrict__ wmax,
                                       u32x4* __restrict__ wplf, u32x4* __restrict__ wplb, int I, int O) {
   constexpr int CP = (C1 + 7) / 8 * 8, KS = CP / 8;
@@ -316,7 +325,16 @@ __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsign
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total_f + total_b; t += gridDim.x * blockDim.x) {
     float v[8];
     u32x4* dst;
-    if (t < total_f) {
+    if (WIDE && t < total_f) {
+      const int lane = t & 63, n = (t >> 6) & 1, f = (t >> 7) % I, by = (t >> 7) / I;
+      const int o = by * 64 + n * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = wide_col(h, e);
+        v[e] = (c < C1) ? wp[((size_t)o * I + f) * C1 + c] * sw : 0.0f;
+      }
+      dst = wplf + ((((size_t)by * I + f) * 2 + n) * 2) * 64 + lane;
+    } else if (t < total_f) {
       const int lane = t & 63, n = (t >> 6) & 3;
       const int ks = (t >> 8) % KS, st = ((t >> 8) / KS) % nst, by = (t >> 8) / (KS * nst);
       const int o = by * 64 + n * 16 + (lane & 15), kb = lane >> 4;
@@ -1938,6 +1956,233 @@ fwd12_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, co
   }
 }
 
+// ---- forward, 12 jets, on 32 x 32 x 16 tiles.  The lone wave a SIMD holds here (192 accumulator registers, a 25 KB E
+// tile) issues a 16 x 16 x 32 instruction every 22 cycles at best; the 32 x 32 x 16 shape keeps the pipe full from one
+// wave and holds the vector issue port for 8 of its 32 cycles.  Same wave tile, E tile, expansion and park as
+// fwd12_f16_kernel: a group of slots (8 points x 4 rows) is one row tile of 32, the 16 padded columns of a feature
+// one k-step; 3 row tiles x 2 output tiles of 32 = 6 accumulator tiles of 16 registers.  A stage = 4 features = 12
+// regions (feature, group) of 6 matrix instructions.  B operands (forward image of pack_wplanes16_kernel<C1, true>):
+// one feature = 4 x 16 bytes per lane, fetched three features ahead; A operands by transposed reads two regions ahead,
+// columns in wide_col order.
+
+struct WFeat32 { u32x4 h[2], l[2]; };                       // B operands of one feature: [n]
+
+template <int C1, int ACT, bool GEN>
+struct Fwd12W {
+  using F = Fwd12<C1, ACT, GEN>;
+  static_assert(F::CP == 16, "one k-step of 16 columns per feature");
+  static constexpr int NR = 12;
+  static constexpr int kFeatVecs = 2 * 2 * 64;             // u32x4 per feature of W planes
+  static constexpr int nk = F::nk;
+
+  static __device__ __forceinline__ void load_w(WFeat32& w, const u32x4* __restrict__ src, int lane, int n) {
+    w.h[n] = src[(n * 2) * 64 + lane];
+    w.l[n] = src[(n * 2 + 1) * 64 + lane];
+  }
+  static __device__ __forceinline__ ATile16 read_a(const unsigned* sE, int off0, int off1, int g) {
+    ATile16 a;
+    a.h = tr_read8(sE + off0 + 16 * g, sE + off1 + 16 * g);
+    a.l = tr_read8(sE + off0 + 16 * g + F::PLANE, sE + off1 + 16 * g + F::PLANE);
+    return a;
+  }
+
+  // region i = (feature i / 3, group i % 3); the expansion of the next stage's pairs as in Fwd12::stage
+  static __device__ __forceinline__ void stage(f32x16 (&acc)[3][2], WFeat32 (&Wr)[4], ATile16& cur, ATile16& nxt,
+                                               f32x4 (&xraw)[3], KnotPre<GEN>& kp, FeatGrid& fg, unsigned* sE,
+                                               const float* knots_next2,
+                                               const SlotScales12& sc, int& prev_c0, const u32x4* __restrict__ wsrc,
+                                               const u32x4* __restrict__ wnext, const char* __restrict__ xnext2,
+                                               const int (&aoff)[4][2], int lane) {
+    const int p_local = lane & 7, f_local = (lane >> 3) & 3;
+    const bool upper = lane >= 32;
+    PairKeep12x pk;
+    RowCoefs12 rc;
+    f32x4 col[3];
+    Planes12 pp[3];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int f = i / 3, g = i % 3;
+      const WFeat32& Wc = Wr[f];
+      if (g < 2) {                             // B operands three features ahead (a ring of four: the slot feature f-1 left)
+        const int t = f + 3;
+        load_w(Wr[t & 3], (t < 4) ? wsrc + t * kFeatVecs : wnext + (t - 4) * kFeatVecs, lane, g);
+      }
+      if (i >= 2 && i <= 4) pp[i - 2] = split_col12(col);           // (the column the region before computed)
+      if (i == 0) {                            // (the knots around the pair were fetched at the end of the stage before)
+        basis_from_knots<GEN>(kp, nk, fg, xraw[0][0], pk.bs);
+        pk.av = eval_act(ACT, xraw[0][0]);
+      }
+      if (i == 1) {
+        rc = row_coefs12(xraw, sc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xraw[q] = *reinterpret_cast<const f32x4*>(xnext2 + 16 * q);
+      }
+      if (i >= 1 && i <= 3) column12_half(pk, rc, i - 1, upper, col);
+      if (i == NR - 2) {
+        unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
+        park_pair12_half<C1, F::PLANE>(base, sE + (F::ROWS - 1) * kRowWords12 + p_local * 2, pp, pk.bs.c0, prev_c0, upper);
+      }
+      if (i == NR - 1) {                       // knots of the pairs of the stage after the next (xraw since region 1)
+        fg = (FeatGrid){knots_next2[0], knots_next2[nk - 1], fabsf(knots_next2[GEN ? nk + 4 : nk])};
+        kp = fetch_knots<GEN>(knots_next2, nk, fg, xraw[0][0]);
+      }
+      const int t2 = (i + 2) % NR;           // (the last two regions read the next stage's first feature)
+      const ATile16 far = read_a(sE, aoff[t2 / 3][0], aoff[t2 / 3][1], t2 % 3);
+      const f16x8 Ah = __builtin_bit_cast(f16x8, cur.h), Al = __builtin_bit_cast(f16x8, cur.l);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, Wc.h[n]), acc[g][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, Wc.l[n]), acc[g][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, Wc.h[n]), acc[g][n], 0, 0, 0);
+      cur = nxt;
+      nxt = far;
+      if (i <= 4) interleave<6, 10>(); else interleave<6, 6>();
+      PDEKAN_REGION_FENCE();
+    }
+  }
+};
+
+template <int C1, int ACT, bool GEN>
+__global__ void __launch_bounds__(256, 1)
+fwd12w_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                  const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
+                  const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
+  using F = Fwd12<C1, ACT, GEN>;
+  using W = Fwd12W<C1, ACT, GEN>;
+  constexpr int KP = F::KP, nk = F::nk;
+  constexpr int kWaveWords = 2 * F::PLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  {
+    bool near = true, equal = true;
+    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+      const float gi = ginfo[i < I ? i : 0];
+      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+    }
+    if (!near || equal == GEN) return;
+  }
+  float* sK = reinterpret_cast<float*>(smem);
+  unsigned* sE = reinterpret_cast<unsigned*>(smem) + I * KP + wave * kWaveWords;
+  if constexpr (GEN) {
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  for (int idx = lane; idx < kWaveWords; idx += 64) sE[idx] = 0u;
+  const SlotScales12 sc = expanded_slot_scales12(amax_in, max_inv_h(ginfo, I, lane));
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  __syncthreads();
+
+  const int r = lane & 31, hq = lane >> 5, p_local = lane & 7, f_local = (lane >> 3) & 3;
+  const int64_t P0 = ((int64_t)blockIdx.x * 4 + wave) * 8;
+  if (P0 >= N) return;
+  const int o0 = blockIdx.y * 64;
+  const int nst = I / 4;
+  // E tile rows of this lane's transposed reads: lane 4q+p of 16-lane group t addresses the row of column
+  // wide_col(t >> 1, 4 * half + q) of the feature, (point, row) block 16 (t & 1) + 4p .. + 3 of the group's 32
+  int aoff[4][2];
+  {
+    const int t = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int c = wide_col(t >> 1, 4 * half + q_);
+        const int row = (c < C1) ? f * C1 + c : F::ROWS - 2;
+        aoff[f][half] = row * kRowWords12 + 8 * (t & 1) + 2 * p_;
+      }
+  }
+  const char* xrow = reinterpret_cast<const char*>(a + ((P0 + p_local) * I + f_local) * 3);
+  constexpr size_t kStageBytes = 4 * 48;                                    // 4 features x 12 floats
+  const u32x4* wbase = wpl + (size_t)blockIdx.y * I * W::kFeatVecs;
+  const float* kbase = sK + f_local * KP + (GEN ? 3 : 0);
+
+  f32x16 acc[3][2], tot[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { acc[g][n][v] = 0.f; tot[g][n][v] = 0.f; }
+
+  WFeat32 Wr[4];
+  int prev_c0 = -100;
+  f32x4 xraw[3];
+  {
+    f32x4 x0[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      x0[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+      xraw[g] = *reinterpret_cast<const f32x4*>(xrow + kStageBytes + 16 * g);
+    }
+    const FeatGrid fg = {kbase[0], kbase[nk - 1], fabsf(kbase[GEN ? nk + 4 : nk])};
+    PairCols12 pj;
+    Planes12 pp[5];
+    expand12<ACT, GEN>(kbase, nk, fg, x0, sc, pj);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) pp[m] = split_col12(pj.col[m]);
+    unsigned* base = sE + (f_local * C1) * kRowWords12 + p_local * 2;
+    park_pair12<C1, F::PLANE>(base, sE + (F::ROWS - 1) * kRowWords12 + p_local * 2, pp, pj.c0, prev_c0);
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      W::load_w(Wr[f], wbase + f * W::kFeatVecs, lane, 0);
+      W::load_w(Wr[f], wbase + f * W::kFeatVecs, lane, 1);
+    }
+  }
+  ATile16 cur = W::read_a(sE, aoff[0][0], aoff[0][1], 0);
+  ATile16 nxt = W::read_a(sE, aoff[0][0], aoff[0][1], 1);
+  FeatGrid fgn;
+  KnotPre<GEN> kpn;
+  {
+    const float* kn = kbase + 4 * (nst > 1 ? 1 : 0) * KP;
+    fgn = (FeatGrid){kn[0], kn[nk - 1], fabsf(kn[GEN ? nk + 4 : nk])};
+    kpn = fetch_knots<GEN>(kn, nk, fgn, xraw[0][0]);
+  }
+  for (int s = 0; s < nst; ++s) {
+    // stages past the end: any valid data, expanded and parked but never multiplied
+    const int s1 = (s + 1 < nst) ? s + 1 : 0, s2 = (s + 2 < nst) ? s + 2 : 0;
+    W::stage(acc, Wr, cur, nxt, xraw, kpn, fgn, sE, kbase + 4 * s2 * KP, sc, prev_c0, wbase + (size_t)s * 4 * W::kFeatVecs,
+             wbase + (size_t)s1 * 4 * W::kFeatVecs, xrow + (size_t)s2 * kStageBytes, aoff, lane);
+    if (((s + 1) % kFwdFlushStages) == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          tot[g][n] += acc[g][n];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[g][n][v] = 0.f;
+        }
+    }
+  }
+  // D[(p, row)][output]: registers 4q .. 4q+3 of tile (g, n) are slots 4g .. 4g+3 of point 2q + hq for output 32n + r
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    f32x4 inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[4 * g + j] * sw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t p = P0 + 2 * q + hq;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const f32x16 t = acc[g][n] + tot[g][n];
+        y[(p * O + o0 + 32 * n + r) * 3 + g] = (f32x4){t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]} * inv;
+      }
+    }
+  }
+}
+
 // ---- input-jet gradients, 12 jets: wave = 8 points x 3 groups = 6 row tiles of gY (A operands, in registers) against
 // the W planes of 64 outputs at a time, as in bwd_input_f16_kernel; a stage = 4 features = NB column tiles x 2
 // k-steps = 2*NB regions of 18 matrix instructions.  The stage's gE tile [8 points][4*CP columns][12 slots] is
@@ -2526,7 +2771,14 @@ void launch_jet_absmax12(const float* t, int64_t elems, unsigned* out12, hipStre
 }
 
 // wp[O][I][C1] -> the two W plane images; wmax: bits of max |wp| (launch_absmax)
-void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st) {
+// 12-jet layers whose forward runs on 32 x 32 x 16 tiles (fwd12w_f16_kernel: its own forward image of the W planes)
+bool f16_wide_forward12(const LayerView& L) {
+  const char* off = getenv("PDEKAN_DISABLE_F16_WIDE");   // A/B switch for tests and profiling
+  return L.G == 10 && !(off && off[0] == '1');
+}
+
+// jets12: the planes are for the 12-jet kernels
+void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st, bool jets12) {
   u32x4* f = reinterpret_cast<u32x4*>(wpl);
   u32x4* b = reinterpret_cast<u32x4*>(wpl + f16_wplane_floats(L) / 2);
   const int cp = cp_of(L);
@@ -2534,8 +2786,9 @@ void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* 
   const int total = (L.O / 64) * ((L.I / 4) * (cp / 8) * 4 + (L.I / 8) * nrp) * 64;
   int blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (L.G == 10) pack_wplanes16_kernel<14><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
-  else pack_wplanes16_kernel<24><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  if (L.G == 10 && jets12 && f16_wide_forward12(L)) pack_wplanes16_kernel<14, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  else if (L.G == 10) pack_wplanes16_kernel<14, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  else pack_wplanes16_kernel<24, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
 }
 
 template <typename Kern>
@@ -2579,7 +2832,7 @@ template <int ACT, bool GEN>
 static void fwd12_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
                          const unsigned* amax_in, const unsigned* wmax, hipStream_t st) {
   using F = Fwd12<14, ACT, GEN>;
-  auto k = fwd12_f16_kernel<14, ACT, GEN>;
+  auto k = f16_wide_forward12(L) ? fwd12w_f16_kernel<14, ACT, GEN> : fwd12_f16_kernel<14, ACT, GEN>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * 2 * F::PLANE) * 4;
   allow_lds(k, lds);
   dim3 g((unsigned)((N + 31) / 32), L.O / 64);

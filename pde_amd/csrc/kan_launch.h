@@ -129,7 +129,7 @@ bool f16_wide_weight_tiles(int D, int D2, const LayerView& L);
 size_t f16_wplane_floats(const LayerView& L);
 void launch_absmax(const float* w, int64_t n, unsigned* out, hipStream_t st);               // out[0] = bits of max |w|
 void launch_jet_absmax(const float* t, int64_t elems, unsigned* out4, hipStream_t st);      // per-jet maxima of [elems][4]
-void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st);
+void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st, bool jets12 = false);
 // amax_in: per-jet maxima of a (4 words); amax_out: where the per-jet maxima of y are combined into, or nullptr
 void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
                     const unsigned* wmax, unsigned* amax_out, hipStream_t st);

@@ -554,7 +554,7 @@ int pack_model(ModelPlan& P, const ModelWs& W, const ModelStats& S, hipStream_t 
     if (W.win[l]) pdekan::launch_pack_window(P.L[l], W.wp[l], W.win[l], st);
     if (W.wpl[l]) {
       pdekan::launch_absmax(W.wp[l], (int64_t)P.L[l].packed_floats(), S.w(l), st);
-      pdekan::launch_pack_wplanes16(P.L[l], W.wp[l], S.w(l), W.wpl[l], st);
+      pdekan::launch_pack_wplanes16(P.L[l], W.wp[l], S.w(l), W.wpl[l], st, P.D == 6);
     }
   }
   return check_launch("pack");
@@ -605,7 +605,7 @@ bool carve_layer(Carver& c, int D, int D2, const pdekan::LayerView& L, bool with
   return c.ok;
 }
 
-int pack_layer(pdekan::LayerView& L, const LayerTables& T, hipStream_t st) {
+int pack_layer(pdekan::LayerView& L, const LayerTables& T, hipStream_t st, int n_dir) {
   pdekan::launch_grid_info(L, T.ginfo, st);
   L.ginfo = T.ginfo;
   pdekan::launch_pack_weights(L, T.wp, T.wt, st);
@@ -614,7 +614,7 @@ int pack_layer(pdekan::LayerView& L, const LayerTables& T, hipStream_t st) {
     if (hipMemsetAsync(T.stats, 0, kLayerStatWords * 4, st) != hipSuccess)
       return fail(PDEKAN_ERR_HIP, "clearing the scale maxima failed");
     pdekan::launch_absmax(T.wp, (int64_t)L.packed_floats(), T.stats + kStatW, st);
-    pdekan::launch_pack_wplanes16(L, T.wp, T.stats + kStatW, T.wpl, st);
+    pdekan::launch_pack_wplanes16(L, T.wp, T.stats + kStatW, T.wpl, st, n_dir == 6);
   }
   return PDEKAN_OK;
 }
@@ -632,7 +632,7 @@ int layer_forward_impl(const PdekanLayer* layer, const float* x_jet, float* y_je
   if (!carve_layer(c, n_dir, n_second, L, true, T))
     return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  rc = pack_layer(L, T, st);
+  rc = pack_layer(L, T, st, n_dir);
   if (rc) return rc;
   F16Io io;
   if (T.wpl) {
@@ -764,7 +764,7 @@ int pdekan_layer_backward(const PdekanLayer* layer, const float* x_jet, const fl
   float* part = c.take(layer_part_floats(n_dir, n_second, L, n));
   if (!tables_ok || !c.ok) return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  rc = pack_layer(L, T, st);
+  rc = pack_layer(L, T, st, n_dir);
   if (rc) return rc;
   F16Io io;
   const bool f16 = T.wpl && n_dir == 2;
