@@ -477,16 +477,19 @@ def test_small_model_step_in_two_launches_equals_the_layer_by_layer_step(widths,
     assert max_rel(grad_s.cpu(), flat_ref) <= TOL
 
 
-@pytest.mark.parametrize("widths,N,moved", [([6, 64, 1], 1, False), ([6, 64, 1], 77, True), ([6, 128, 64, 1], 4101, False),
-                                            ([6, 256, 1], 300, False), ([6, 128, 128, 1], 20000, True)])
-def test_first_layer_kernels_of_the_basket_model(widths, N, moved, monkeypatch):
+@pytest.mark.parametrize("widths,N,moved,G", [([6, 64, 1], 1, False, 10), ([6, 64, 1], 77, True, 10),
+                                              ([6, 128, 64, 1], 4101, False, 10), ([6, 256, 1], 300, False, 10),
+                                              ([6, 128, 128, 1], 20000, True, 10), ([6, 64, 1], 1234, False, 5),
+                                              ([6, 128, 1], 999, False, 20), ([6, 64, 1], 515, True, 20)])
+def test_first_layer_kernels_of_the_basket_model(widths, N, moved, G, monkeypatch):
     """The first layer of a 12-jet model (6 inputs = 6 directions: its input jets are seeds) has a forward and a
     weight-gradient kernel of its own: 85 multiply-adds per output jet, weights in LDS, weight gradients summed in
-    LDS per chunk.  One point, batches with dead points, 64 to 256 outputs, a first layer whose knots update_grid
-    has moved, a target: same step as with those kernels switched off (PDEKAN_DISABLE_SEEDED_FIRST=1: the streaming
-    kernels), as the fp64 oracle, and bit for bit the same from run to run."""
+    registers per chunk.  One point, batches with dead points, 64 to 256 outputs, grid sizes 5, 10 and 20 (a kernel
+    each), a first layer whose knots update_grid has moved, a target: same step as with those kernels switched off
+    (PDEKAN_DISABLE_SEEDED_FIRST=1: the streaming kernels), as the fp64 oracle, and bit for bit the same from run to
+    run."""
     from pde_amd.pinn import BlackScholesStep
-    m = _random_model(widths, 10, 41 + N % 5)
+    m = _random_model(widths, G, 41 + N % 5)
     gen = torch.Generator().manual_seed(N)
     x = torch.rand(N, 6, generator=gen)
     target = 0.1 * torch.randn(N, generator=gen)
