@@ -165,6 +165,24 @@ def test_fp16_kernels_with_12_jets_agree_with_the_streaming_kernels(I, O_, N, kn
         assert not torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1]) and not torch.equal(a[3], b[3])
 
 
+@pytest.mark.parametrize("I,O_,N,knots", [(128, 128, 2064, "default"), (64, 64, 8, "default"), (96, 256, 535, "jittered")])
+def test_12_jet_forward_on_wide_tiles_agrees_with_the_narrow_tiles(I, O_, N, knots, monkeypatch):
+    """The 12-jet forward runs on 32 x 32 x 16 matrix tiles with its own image of the W planes; with
+    PDEKAN_DISABLE_F16_WIDE=1 the 16 x 16 x 32 kernel and its image are used.  Same outputs to fp32 reassociation
+    (the products are the same, the order of the sums is not); the backward kernels are the same either way."""
+    lay = _layer(I, O_, 10, knots, I + O_ + 3)
+    xj, gy = _jets12(N, I, O_, N + 2)
+    a = _run12(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16_WIDE", "1")
+    b = _run12(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16_WIDE")
+    for j in range(12):
+        assert max_rel(a[0][..., j].cpu(), b[0][..., j].cpu()) <= 2e-6, ("y", j)
+    assert not torch.equal(a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+
+
 def test_12_jet_layers_with_moved_knots_fall_back(monkeypatch):
     """Knot rows far from equal spacing: the matrix kernels step aside on the device and the streaming kernels
     launched beside them do the layer.  Outputs and input gradients are theirs bit for bit; the weight gradients are
