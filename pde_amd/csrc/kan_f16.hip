@@ -46,6 +46,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kF16Target = 13;               // scaled maxima sit in [2^12, 2^13): 8x headroom under fp16's 65504
 constexpr int kKnotPadU = 28;                // staged knot row, equally spaced: G+7 knots + 1/h, G <= 20
 constexpr int kKnotPadN = 36;                // nearly equally spaced: 3 + 4 repeated end knots around the G+7 knots
+// the same for the kernels that stage the rows of the whole layer (a grid-10 row of either kind fits 28 words: the two
+// variants of a kernel then ask for the same LDS and can share a launch without costing the equally spaced one a
+// resident block)
+constexpr int layer_knot_pad(int nk, bool gen) { return gen ? (nk + 8 <= kKnotPadU ? kKnotPadU : kKnotPadN) : kKnotPadU; }
 
 // ---- scales ---------------------------------------------------------------------------------------------
 // 2^k with bound * 2^k in [2^(target-1), 2^target); bound = 0 or denormal gives the largest scale allowed
@@ -394,7 +398,7 @@ struct FwdF16 {
   static constexpr int NR = 4 * KS;                        // regions (k-step, m-tile) per stage
   static constexpr int ROWS = 4 * C1 + 1;                  // + one row of zeros for the pad columns
   static constexpr int PLANE = ROWS * kRowWords;
-  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int KP = layer_knot_pad(C1 + 3, GEN);
   static constexpr int nk = C1 + 3;
   static constexpr int kStepVecs = 4 * 2 * 64;             // u32x4 per k-step of W planes
   static constexpr int kStageVecs = KS * kStepVecs;
@@ -480,26 +484,28 @@ struct FwdF16 {
 constexpr int kFwdFlushStages = 8;
 constexpr int kFwdChainMax = 128;            // matrix instructions chained on one accumulator without LONGK
 
+// 0: some knot row of the layer is far from equal spacing (the kernel launched beside does the layer); 1: every row
+// equally spaced; 2: at least nearly so.  Block-uniform.
+__device__ __forceinline__ int layer_knot_class(const float* __restrict__ ginfo, int I, int lane) {
+  bool near = true, equal = true;
+  for (int i = lane; i < ((I + 63) & ~63); i += 64) {
+    const float gi = ginfo[i < I ? i : 0];
+    near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
+    equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
+  }
+  return !near ? 0 : (equal ? 1 : 2);
+}
+
 template <int C1, int ACT, bool GEN, bool LONGK>
-__global__ void __launch_bounds__(256, LONGK ? 1 : 2)
-fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
-               const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
-               const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
+__device__ __forceinline__ void
+fwd_f16_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+             const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
+             const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
   using F = FwdF16<C1, ACT, GEN>;
   constexpr int KS = F::KS, KP = F::KP, nk = F::nk, CP = F::CP;
   constexpr int kWaveWords = 2 * F::PLANE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // block-uniform: every feature's knots at least nearly equally spaced; GEN = false takes the layer when all are equal
-  {
-    bool near = true, equal = true;
-    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
-      const float gi = ginfo[i < I ? i : 0];
-      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
-      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
-    }
-    if (!near || equal == GEN) return;
-  }
   float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
   unsigned* sE = reinterpret_cast<unsigned*>(smem) + I * KP + wave * kWaveWords;   // this wave's E tile
   if constexpr (GEN) {                       // [g_0 x3][the nk knots][g_last x4][1/h]
@@ -621,6 +627,19 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
   }
 }
 
+// One launch for both variants (a second launch that only finds out it has nothing to do still costs 12-20 us at
+// 2^20 points: its blocks ask for the same 146 KB of LDS and pass through the CUs one at a time): the block takes the
+// variant that matches the layer's knot rows, or returns when a row is far from equal spacing.
+template <int C1, int ACT, bool LONGK>
+__global__ void __launch_bounds__(256, LONGK ? 1 : 2)
+fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+               const u32x4* __restrict__ wpl, f32x4* __restrict__ y, int64_t N, int I, int O,
+               const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
+  const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
+  if (cls == 1) fwd_f16_body<C1, ACT, false, LONGK>(a, grid, ginfo, wpl, y, N, I, O, amax_in, wmax, amax_out);
+  else if (cls == 2) fwd_f16_body<C1, ACT, true, LONGK>(a, grid, ginfo, wpl, y, N, I, O, amax_in, wmax, amax_out);
+}
+
 // ==========================================================================================================
 // input-jet gradients.  gE[(p, j)][k] = sum_o gY[(p, j)][o] * W[o][k]: M = (point, jet), K = 64 outputs (2 k-steps),
 // N = 16 columns.  Wave = 16 points; the A operands (the wave's gY rows, cut into planes once) stay in registers,
@@ -638,7 +657,7 @@ struct BwiF16 {
   static constexpr int ROW = BwiTiles<C1>::RING * 4 + 4;   // words per point in the parked gE tile (+4: bank spread)
   static constexpr int GROW = 64 * 4 + 4;                  // words per point of the staged raw gY rows
   static constexpr int TILE = 16 * (ROW > GROW ? ROW : GROW);
-  static constexpr int KP = GEN ? kKnotPadN : kKnotPadU;
+  static constexpr int KP = layer_knot_pad(C1 + 3, GEN);
   static constexpr int nk = C1 + 3;
 };
 
@@ -684,26 +703,17 @@ __device__ __forceinline__ f32x4 chain_rule(const PairBack& pb, const f32x4 (&dc
 // N must be a multiple of 16 (whole waves; the caller gives the last N % 16 points to the sparse kernel).
 // MULTI: more than 64 outputs (several passes, read-modify-write of ga).
 template <int C1, int ACT, bool GEN, bool MULTI>
-__global__ void __launch_bounds__(256, 2)
-bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
-                     const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
-                     int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
-                     unsigned* __restrict__ cot_out) {
+__device__ __forceinline__ void
+bwd_input_f16_body(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                   const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
+                   int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
+                   unsigned* __restrict__ cot_out) {
   using F = BwiF16<C1, ACT, GEN>;
   using T = BwiTiles<C1>;
   constexpr int KP = F::KP, nk = F::nk, ROW = F::ROW, GROW = F::GROW;
   constexpr int C = C1 - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  {
-    bool near = true, equal = true;
-    for (int i = lane; i < ((I + 63) & ~63); i += 64) {
-      const float gi = ginfo[i < I ? i : 0];
-      near = near && (__builtin_amdgcn_ballot_w64(gi != 0.0f) == ~0ull);
-      equal = equal && (__builtin_amdgcn_ballot_w64(gi > 0.0f) == ~0ull);
-    }
-    if (!near || equal == GEN) return;
-  }
   float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
   float* sD = sK + I * KP + wave * F::TILE;                                 // this wave's tile
   if constexpr (GEN) {
@@ -894,6 +904,18 @@ bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, 
     }
   }
   if (cot_out) publish_jet_max(vmax, cot_out, lane);
+}
+
+// both variants in one launch, as in fwd_f16_kernel
+template <int C1, int ACT, bool MULTI>
+__global__ void __launch_bounds__(256, 2)
+bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                     const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
+                     int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
+                     unsigned* __restrict__ cot_out) {
+  const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
+  if (cls == 1) bwd_input_f16_body<C1, ACT, false, MULTI>(a, gy, grid, ginfo, wpl, ga, N, I, O, cot_in, wmax, cot_out);
+  else if (cls == 2) bwd_input_f16_body<C1, ACT, true, MULTI>(a, gy, grid, ginfo, wpl, ga, N, I, O, cot_in, wmax, cot_out);
 }
 
 // ==========================================================================================================
@@ -2796,12 +2818,12 @@ static void allow_lds(Kern k, size_t bytes) {
   ensure_dynamic_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
-template <int C1, int ACT, bool GEN>
+template <int C1, int ACT>
 static void fwd_f16_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
                            const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
-  using F = FwdF16<C1, ACT, GEN>;
+  using F = FwdF16<C1, ACT, true>;             // (the nearly-equal variant's knot rows are the longer ones)
   const bool longk = (L.I / 4) * F::KS * 3 > kFwdChainMax;
-  auto k = longk ? fwd_f16_kernel<C1, ACT, GEN, true> : fwd_f16_kernel<C1, ACT, GEN, false>;
+  auto k = longk ? fwd_f16_kernel<C1, ACT, true> : fwd_f16_kernel<C1, ACT, false>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * 2 * F::PLANE) * 4;
   allow_lds(k, lds);
   dim3 g((unsigned)((N + 63) / 64), L.O / 64);
@@ -2812,16 +2834,11 @@ static void fwd_f16_launch(const LayerView& L, const float* a, const float* wpl,
 template <int C1>
 static void fwd_f16_variants(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
                              const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
-  if (L.act == kActSiLU) {
-    fwd_f16_launch<C1, kActSiLU, false>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
-    fwd_f16_launch<C1, kActSiLU, true>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
-  } else {
-    fwd_f16_launch<C1, kActIdentity, false>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
-    fwd_f16_launch<C1, kActIdentity, true>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
-  }
+  if (L.act == kActSiLU) fwd_f16_launch<C1, kActSiLU>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  else fwd_f16_launch<C1, kActIdentity>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
 }
 
-// both variants on the same grid; the one that matches the layer's knot rows runs, the other returns at once
+// one launch: a block takes the variant that matches the layer's knot rows (or returns at once)
 void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
                     const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
   if (L.G == 10) fwd_f16_variants<14>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
@@ -2878,11 +2895,11 @@ void launch_bwd_input12_f16(const LayerView& L, const float* a, const float* gy,
   }
 }
 
-template <int C1, int ACT, bool GEN>
+template <int C1, int ACT>
 static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                            const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
-  using F = BwiF16<C1, ACT, GEN>;
-  auto k = (L.O > 64) ? bwd_input_f16_kernel<C1, ACT, GEN, true> : bwd_input_f16_kernel<C1, ACT, GEN, false>;
+  using F = BwiF16<C1, ACT, true>;             // (the nearly-equal variant's knot rows are the longer ones)
+  auto k = (L.O > 64) ? bwd_input_f16_kernel<C1, ACT, true> : bwd_input_f16_kernel<C1, ACT, false>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * F::TILE) * 4;
   allow_lds(k, lds);
   k<<<(unsigned)((N + 63) / 64), 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(gy),
@@ -2893,13 +2910,8 @@ static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, 
 template <int C1>
 static void bwi_f16_variants(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                              const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
-  if (L.act == kActSiLU) {
-    bwi_f16_launch<C1, kActSiLU, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
-    bwi_f16_launch<C1, kActSiLU, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
-  } else {
-    bwi_f16_launch<C1, kActIdentity, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
-    bwi_f16_launch<C1, kActIdentity, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
-  }
+  if (L.act == kActSiLU) bwi_f16_launch<C1, kActSiLU>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  else bwi_f16_launch<C1, kActIdentity>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
 }
 
 // cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr.
