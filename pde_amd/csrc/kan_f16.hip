@@ -703,17 +703,20 @@ __device__ __forceinline__ f32x4 chain_rule(const PairBack& pb, const f32x4 (&dc
 // N must be a multiple of 16 (whole waves; the caller gives the last N % 16 points to the sparse kernel).
 // MULTI: more than 64 outputs (several passes, read-modify-write of ga).
 template <int C1, int ACT, bool GEN, bool MULTI>
-__device__ __forceinline__ void
-bwd_input_f16_body(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
-                   const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
-                   int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
-                   unsigned* __restrict__ cot_out) {
+__global__ void __launch_bounds__(256, 2)
+bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
+                     const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
+                     int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
+                     unsigned* __restrict__ cot_out) {
   using F = BwiF16<C1, ACT, GEN>;
   using T = BwiTiles<C1>;
   constexpr int KP = F::KP, nk = F::nk, ROW = F::ROW, GROW = F::GROW;
   constexpr int C = C1 - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // (the two variants stay separate launches here: with both bodies in one kernel, as in the forward, the grid-20
+  // instantiations keep a pair's basis in scratch memory and lose 5 %)
+  if (layer_knot_class(ginfo, I, lane) != (GEN ? 2 : 1)) return;
   float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
   float* sD = sK + I * KP + wave * F::TILE;                                 // this wave's tile
   if constexpr (GEN) {
@@ -904,18 +907,6 @@ bwd_input_f16_body(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, co
     }
   }
   if (cot_out) publish_jet_max(vmax, cot_out, lane);
-}
-
-// both variants in one launch, as in fwd_f16_kernel
-template <int C1, int ACT, bool MULTI>
-__global__ void __launch_bounds__(256, 2)
-bwd_input_f16_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ gy, const float* __restrict__ grid,
-                     const float* __restrict__ ginfo, const u32x4* __restrict__ wpl, f32x4* __restrict__ ga, int64_t N,
-                     int I, int O, const unsigned* __restrict__ cot_in, const unsigned* __restrict__ wmax,
-                     unsigned* __restrict__ cot_out) {
-  const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
-  if (cls == 1) bwd_input_f16_body<C1, ACT, false, MULTI>(a, gy, grid, ginfo, wpl, ga, N, I, O, cot_in, wmax, cot_out);
-  else if (cls == 2) bwd_input_f16_body<C1, ACT, true, MULTI>(a, gy, grid, ginfo, wpl, ga, N, I, O, cot_in, wmax, cot_out);
 }
 
 // ==========================================================================================================
@@ -2895,11 +2886,11 @@ void launch_bwd_input12_f16(const LayerView& L, const float* a, const float* gy,
   }
 }
 
-template <int C1, int ACT>
+template <int C1, int ACT, bool GEN>
 static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                            const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
-  using F = BwiF16<C1, ACT, true>;             // (the nearly-equal variant's knot rows are the longer ones)
-  auto k = (L.O > 64) ? bwd_input_f16_kernel<C1, ACT, true> : bwd_input_f16_kernel<C1, ACT, false>;
+  using F = BwiF16<C1, ACT, GEN>;
+  auto k = (L.O > 64) ? bwd_input_f16_kernel<C1, ACT, GEN, true> : bwd_input_f16_kernel<C1, ACT, GEN, false>;
   const size_t lds = ((size_t)L.I * F::KP + 4 * F::TILE) * 4;
   allow_lds(k, lds);
   k<<<(unsigned)((N + 63) / 64), 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(gy),
@@ -2910,8 +2901,13 @@ static void bwi_f16_launch(const LayerView& L, const float* a, const float* gy, 
 template <int C1>
 static void bwi_f16_variants(const LayerView& L, const float* a, const float* gy, const float* wplb, float* ga, int64_t N,
                              const unsigned* cot_in, const unsigned* wmax, unsigned* cot_out, hipStream_t st) {
-  if (L.act == kActSiLU) bwi_f16_launch<C1, kActSiLU>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
-  else bwi_f16_launch<C1, kActIdentity>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  if (L.act == kActSiLU) {
+    bwi_f16_launch<C1, kActSiLU, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+    bwi_f16_launch<C1, kActSiLU, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  } else {
+    bwi_f16_launch<C1, kActIdentity, false>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+    bwi_f16_launch<C1, kActIdentity, true>(L, a, gy, wplb, ga, N, cot_in, wmax, cot_out, st);
+  }
 }
 
 // cot_in: per-jet maxima of gy (4 words); cot_out: where the per-jet maxima of ga are combined into, or nullptr.
