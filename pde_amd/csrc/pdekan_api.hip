@@ -584,8 +584,10 @@ int model_layer_forward(const ModelPlan& P, const ModelWs& W, const ModelStats& 
   // a layer the sparse kernel takes can leave the maxima of its outputs for an fp16 matrix layer above as well
   unsigned* sparse_out = nullptr;
   if (!f16 && l + 1 < nl && W.wpl[l + 1] && W.win[l] && pdekan::sparse_eligible(P.D, P.D2, P.L[l])) sparse_out = S.act(l + 1);
-  // and so can a 12-jet layer on the streaming kernel (the first layer of a 6-input model)
-  if (!f16 && P.D == 6 && l + 1 < nl && W.wpl[l + 1]) sparse_out = S.act(l + 1);
+  // and so can a layer on the streaming kernel (the first layer of a 6-input model, or of a grid-20 model)
+  const bool streams = !f16 && !(W.win[l] && pdekan::sparse_eligible(P.D, P.D2, P.L[l])) &&
+                       !pdekan::mfma_eligible(P.D, P.D2, P.L[l]);
+  if (streams && (P.D == 6 || P.D == 2) && l + 1 < nl && W.wpl[l + 1]) sparse_out = S.act(l + 1);
   *act_ready = (f16 && io.act_out != nullptr) || sparse_out != nullptr;
   return run_forward(P.D, P.D2, P.L[l], W.act[l], W.wt[l], W.win[l], dst, m, st, l, f16 ? &io : nullptr, sparse_out, seed);
 }
