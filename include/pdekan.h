@@ -152,6 +152,34 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
                    float rate, float* loss_out, float* res_out, const PdekanLayerGrad* grads,
                    int32_t accumulate, int64_t micro_batch, void* ws, size_t ws_bytes, void* stream);
 
+/* One training step of the physics-informed DeepONet the scripts build around four KANs, without the optimiser
+ * update (class PI_DeepONet, run1.py:75-149; loop body run1.py:217-233; networks run1.py:478-482):
+ *   v[r]      = model1(u1[r]) * model2(u2[r])            one value per sensor row, run1.py:92-98
+ *   B         = model4(v as ONE row of `sensors` inputs)  run1.py:111-113 (the script repeats the row n times)
+ *   s(x, t)   = sum_k B[k] * model5(x, t)[k]              run1.py:114-117
+ *   bc loss   = mean((out_bc - s)^2)                      run1.py:134-141
+ *   pde loss  = mean((out_pde - res)^2), res = s_t - sigma^2/2 x^2 s_xx - rate x s_x + rate s   run1.py:120-129, :145-149
+ *   losses[3] = { pde loss + bc_weight * bc loss (run1.py:224), pde loss, bc loss }
+ * and, if the networks carry gradient pointers, what loss.backward() (run1.py:225) leaves in every parameter's
+ * gradient (overwritten, not accumulated).  nets[4] = model1, model2, model4, model5; u1 [sensors][in of model1] and
+ * u2 [sensors][in of model2] contiguous; x, t, out of the boundary batch [n_bc] and of the collocation batch [n_pde]
+ * contiguous.  s_pred [n_bc] and res_out [n_pde] may be NULL.  The step runs in four launches whatever the sizes;
+ * it takes networks whose layers are no wider than 8 (any number of inputs to model4's first layer, one per sensor
+ * row), at most 4 layers each, grid_size <= 20, at most 65536 points in all.  pdekan_deeponet_workspace_bytes
+ * returns 0 for anything else (pdekan_last_error says what) and callers then run the networks layer by layer. */
+typedef struct PdekanNet {
+  const PdekanLayer* layers;
+  const PdekanLayerGrad* grads;    /* one per layer, or NULL: losses only (all four networks alike) */
+  int32_t n_layers;
+  int32_t reserved;
+} PdekanNet;
+size_t pdekan_deeponet_workspace_bytes(const PdekanNet* nets, int64_t sensors, int64_t n_bc, int64_t n_pde);
+int pdekan_deeponet_step(const PdekanNet* nets, const float* u1, const float* u2, int64_t sensors,
+                         const float* x_bc, const float* t_bc, const float* out_bc, int64_t n_bc,
+                         const float* x_pde, const float* t_pde, const float* out_pde, int64_t n_pde,
+                         float sigma, float rate, float bc_weight, float* losses, float* s_pred, float* res_out,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* Optional per-kernel timing for benchmarks (no counterpart in the reference,
  * which only prints a whole-script wall time, run1.py:524-526).  Between
  * begin and end every kernel launched by the calls above is bracketed by HIP

@@ -40,6 +40,15 @@ class PdekanLayerGrad(ctypes.Structure):
     ]
 
 
+class PdekanNet(ctypes.Structure):
+    _fields_ = [
+        ("layers", ctypes.POINTER(PdekanLayer)),
+        ("grads", ctypes.POINTER(PdekanLayerGrad)),
+        ("n_layers", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/pdekan.h declares
 SIGNATURES = {
     "pdekan_version": (ctypes.c_int, []),
@@ -78,6 +87,14 @@ SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.POINTER(PdekanLayerGrad), ctypes.c_int32,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "pdekan_deeponet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(PdekanNet), ctypes.c_int64, ctypes.c_int64,
+                                                          ctypes.c_int64]),
+    "pdekan_deeponet_step": (ctypes.c_int, [ctypes.POINTER(PdekanNet), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p]),
     "pdekan_profile_begin": (ctypes.c_int, []),
     "pdekan_profile_end": (ctypes.c_int, []),
     "pdekan_profile_count": (ctypes.c_int, []),

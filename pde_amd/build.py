@@ -16,7 +16,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdekan.so")
-SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "kan_f16.hip", "kan_small.hip", "pdekan_api.hip"]
+SOURCES = ["kan_kernels.hip", "kan_mfma.hip", "kan_head.hip", "kan_sparse.hip", "kan_f16.hip", "kan_small.hip", "kan_deeponet.hip",
+           "pdekan_api.hip"]
 # kan_f16.hip: without the SLP vectorizer.  With it, hipcc 7.2 (-O3, gfx950) builds the 12-jet weight-gradient kernel
 # into code whose expanded columns come out wrong in lanes 48..63 (first element of each packed pair), whatever the
 # source-level form of the expansion; the explicit vector types in the kernels are packed by legalization regardless.

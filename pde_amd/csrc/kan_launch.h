@@ -106,6 +106,19 @@ void launch_small_step(const LayerView* layers, const SmallGrads* grads, int nl,
                        const float* target, int64_t N, float sigma, float rate, float inv_n, float* res_out,
                        float* loss_out, float* part, int accumulate, hipStream_t st);
 
+// kan_deeponet.hip: one training step of the physics-informed DeepONet of run1.py:75-149 (sensor networks model1 and
+// model2, mixing network model4, trunk model5; all layers but model4's first no wider than 8) in four launches
+constexpr int kDonLayersMax = 4;
+struct DonNetView { const LayerView* layers; const SmallGrads* grads; int nl; };   // grads: one per layer, or nullptr
+// nullptr when the four networks (model1, model2, model4, model5) and sizes fit the kernels, else the reason
+const char* deeponet_step_refusal(const DonNetView nets[4], int64_t sensors, int64_t n_bc, int64_t n_pde);
+size_t deeponet_step_ws_floats(const DonNetView nets[4], int64_t sensors, int64_t n_bc, int64_t n_pde);   // 0: refused
+// losses[3] = (pde + bc_weight * bc, pde, bc); s_pred [n_bc], res_out [n_pde] and losses may be nullptr
+bool launch_deeponet_step(const DonNetView nets[4], const float* u1, const float* u2, int64_t sensors, const float* x_bc,
+                          const float* t_bc, const float* out_bc, int64_t n_bc, const float* x_pde, const float* t_pde,
+                          const float* out_pde, int64_t n_pde, float sigma, float rate, float bc_weight, float* losses,
+                          float* s_pred, float* res_out, float* ws, hipStream_t st);
+
 // kan_sparse.hip: sparse-support VALU path for hidden layers (J = 4 jets): forward and input gradients
 bool sparse_eligible(int D, int D2, const LayerView& L);
 bool sparse_input_grad_eligible(int D, int D2, const LayerView& L);

@@ -108,6 +108,32 @@ int to_view(const PdekanLayer* l, pdekan::LayerView& v) {
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// the four networks of pdekan_deeponet_step as the kernels' launcher takes them
+struct DeepONetArgs {
+  pdekan::LayerView layers[4][pdekan::kDonLayersMax];
+  pdekan::SmallGrads grads[4][pdekan::kDonLayersMax];
+  pdekan::DonNetView views[4];
+};
+int deeponet_args(const PdekanNet* nets, DeepONetArgs& A) {
+  if (!nets) return fail(PDEKAN_ERR_ARG, "deeponet_step: nets is NULL");
+  for (int k = 0; k < 4; ++k) {
+    const PdekanNet& N = nets[k];
+    if (!N.layers || N.n_layers < 1 || N.n_layers > pdekan::kDonLayersMax)
+      return fail(PDEKAN_ERR_ARG, "deeponet_step: network %d has %d layers (1 .. %d)", k, N.n_layers, pdekan::kDonLayersMax);
+    for (int l = 0; l < N.n_layers; ++l) {
+      const int rc = to_view(&N.layers[l], A.layers[k][l]);
+      if (rc) return rc;
+      if (N.grads) {
+        if (!N.grads[l].base_weight || !N.grads[l].spline_weight || (A.layers[k][l].scaler && !N.grads[l].spline_scaler))
+          return fail(PDEKAN_ERR_ARG, "deeponet_step: gradient pointers missing");
+        A.grads[k][l] = {N.grads[l].base_weight, N.grads[l].spline_weight, N.grads[l].spline_scaler};
+      }
+    }
+    A.views[k] = {A.layers[k], N.grads ? A.grads[k] : nullptr, N.n_layers};
+  }
+  return PDEKAN_OK;
+}
+
 // bump allocator over the caller's workspace
 struct Carver {
   char* base; size_t size, used = 0; bool ok = true;
@@ -974,6 +1000,38 @@ int pdekan_bs_step(const PdekanLayer* layers, int32_t n_layers, const float* x, 
     first = false;
   }
   return check_launch("bs_step");
+}
+
+size_t pdekan_deeponet_workspace_bytes(const PdekanNet* nets, int64_t sensors, int64_t n_bc, int64_t n_pde) {
+  DeepONetArgs A;
+  if (deeponet_args(nets, A)) return 0;
+  if (const char* why = pdekan::deeponet_step_refusal(A.views, sensors, n_bc, n_pde)) {
+    fail(PDEKAN_ERR_ARG, "deeponet_step: %s", why);
+    return 0;
+  }
+  return pdekan::deeponet_step_ws_floats(A.views, sensors, n_bc, n_pde) * sizeof(float) + 256;
+}
+
+int pdekan_deeponet_step(const PdekanNet* nets, const float* u1, const float* u2, int64_t sensors, const float* x_bc,
+                         const float* t_bc, const float* out_bc, int64_t n_bc, const float* x_pde, const float* t_pde,
+                         const float* out_pde, int64_t n_pde, float sigma, float rate, float bc_weight, float* losses,
+                         float* s_pred, float* res_out, void* ws, size_t ws_bytes, void* stream) {
+  DeepONetArgs A;
+  int rc = deeponet_args(nets, A);
+  if (rc) return rc;
+  if (!u1 || !u2 || !x_bc || !t_bc || !out_bc || !x_pde || !t_pde || !out_pde)
+    return fail(PDEKAN_ERR_ARG, "deeponet_step: NULL buffers");
+  if (const char* why = pdekan::deeponet_step_refusal(A.views, sensors, n_bc, n_pde))
+    return fail(PDEKAN_ERR_ARG, "deeponet_step: %s", why);
+  if (!ws || ((uintptr_t)ws & 255)) return fail(PDEKAN_ERR_WORKSPACE, "workspace NULL or not 256-byte aligned");
+  if (pdekan::deeponet_step_ws_floats(A.views, sensors, n_bc, n_pde) * sizeof(float) > ws_bytes)
+    return fail(PDEKAN_ERR_WORKSPACE, "workspace too small: %zu bytes given", ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, "deeponet_step", 0);
+  if (!pdekan::launch_deeponet_step(A.views, u1, u2, sensors, x_bc, t_bc, out_bc, n_bc, x_pde, t_pde, out_pde, n_pde,
+                                    sigma, rate, bc_weight, losses, s_pred, res_out, static_cast<float*>(ws), st))
+    return fail(PDEKAN_ERR_ARG, "deeponet_step: refused");
+  return check_launch("deeponet_step");
 }
 
 int pdekan_profile_begin(void) {

@@ -58,17 +58,115 @@ def test_losses_and_gradients_match_reference(golden, case):
 
 
 @pytest.mark.parametrize("case", DEEPONET_CASES)
-def test_adamw_steps_follow_the_reference(golden, case):
-    """Three AdamW(lr=0.01) steps of the loop body run1.py:217-233: the loss
-    trace and one updated tensor."""
+def test_one_call_step_matches_reference(golden, case):
+    """pdekan_deeponet_step (the whole step in four launches): predictions, residuals, the three losses and every
+    gradient against the fixtures of the reference formulation."""
+    from pde_amd.deeponet import DeepONetStep
     rec = golden(case)
     net = build(rec)
+    u1, u2, bc, pde = tensors(rec)
+    step = DeepONetStep(net)
+    assert step.supported()
+    s_pred, res = torch.empty_like(bc[0]), torch.empty_like(pde[0])
+    losses = step(u1, u2, bc, pde, s_pred=s_pred, res_out=res)
+    assert losses is not None and step.calls == 1
+    check(s_pred, rec, "s_pred")
+    check(res, rec, "res")
+    check(losses[0], rec, "loss")
+    check(losses[1], rec, "pde_loss")
+    check(losses[2], rec, "bc_loss")
+    for mname in DEEPONET_MODELS:
+        for pname, p in getattr(net, mname).named_parameters():
+            check(p.grad, rec, f"grad.{mname}.{pname}")
+    first = [p.grad.clone() for p in net.parameters()]
+    l0 = losses.clone()
+    step(u1, u2, bc, pde)
+    assert torch.equal(l0, step.losses)                          # fixed summation orders: the same bits every time
+    assert all(torch.equal(a, p.grad) for a, p in zip(first, net.parameters()))
+
+
+def _random_deeponet(widths12, widths4, widths5, grid, act, seed):
+    from pde_amd import KAN
+    from pde_amd.deeponet import PI_DeepONet
+    torch.manual_seed(seed)
+    mk = lambda w: KAN(w, grid_size=grid, base_activation=act)
+    net = PI_DeepONet(mk(widths12), mk(widths12), mk(widths4), mk(widths5), bc_weight=8.0).cuda()
+    with torch.no_grad():
+        for p in net.parameters():                                # off the small default spline weights
+            p.add_(0.3 * torch.randn_like(p))
+    return net
+
+
+@pytest.mark.parametrize("widths12,widths4,widths5,grid,act,m,n_bc,n_pde", [
+    ([3, 2, 1], [1000, 2, 1], [2, 6, 1], 5, torch.nn.Identity, 1000, 100, 100),      # run1.py:478-482 at P = 3000
+    ([3, 2, 1], [3000, 2, 1], [2, 6, 1], 5, torch.nn.Identity, 3000, 100, 100),      # the script's own sizes
+    ([3, 4, 4, 1], [257, 4, 3, 2], [2, 8, 8, 2], 10, torch.nn.SiLU, 257, 33, 70),    # deeper, SiLU, ragged sizes
+    ([2, 1], [64, 3], [2, 3], 20, torch.nn.SiLU, 64, 1, 300),                         # one-layer networks, grid 20
+    ([3, 8, 8, 1], [40, 8, 8], [2, 8, 8, 8], 5, torch.nn.Identity, 40, 700, 5),       # 64 edges per layer
+])
+def test_one_call_step_agrees_with_the_layerwise_path(widths12, widths4, widths5, grid, act, m, n_bc, n_pde):
+    """The one-call step against the same step run layer by layer under autograd (the path the fixtures pin), on
+    networks and batch sizes the fixtures do not cover."""
+    from pde_amd.deeponet import DeepONetStep
+    net = _random_deeponet(widths12, widths4, widths5, grid, act, seed=m)
+    g = torch.Generator().manual_seed(m + 1)
+    r = lambda *shape: torch.rand(*shape, generator=g).cuda()
+    u1, u2 = r(m, widths12[0]) * 1.6 - 0.8, r(m, widths12[0]) * 1.6 - 0.8
+    bc = (r(n_bc) * 1.9 - 0.95, r(n_bc) * 1.9 - 0.95, r(n_bc))
+    pde = (r(n_pde) * 1.9 - 0.95, r(n_pde) * 1.9 - 0.95, 0.1 * r(n_pde))
+    bc_loss = net.loss_bcs(u1, u2, None, None, *bc)
+    pde_loss = net.loss_res(u1, u2, None, None, *pde)
+    loss = pde_loss + net.bc_weight * bc_loss
+    loss.backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    step = DeepONetStep(net)
+    losses = step(u1, u2, bc, pde)
+    assert losses is not None
+    assert max_rel(losses.cpu(), torch.stack([loss, pde_loss, bc_loss]).detach().cpu()) <= 2e-5
+    for (name, p), w in zip(net.named_parameters(), want):
+        assert max_rel(p.grad.cpu(), w.cpu()) <= 5e-5, (name, max_rel(p.grad.cpu(), w.cpu()))
+
+
+def test_one_call_step_refuses_what_it_cannot_hold(monkeypatch):
+    """Networks wider than the kernels hold, and the A/B switch: train_step then runs layer by layer, same numbers."""
+    from pde_amd.deeponet import DeepONetStep
+    net = _random_deeponet([3, 2, 1], [50, 2, 1], [2, 12, 1], 5, torch.nn.Identity, seed=3)     # 24 edges in a layer > 8 wide
+    g = torch.Generator().manual_seed(5)
+    r = lambda *shape: torch.rand(*shape, generator=g).cuda()
+    u1, u2 = r(50, 3), r(50, 3)
+    bc, pde = (r(20), r(20), r(20)), (r(20), r(20), r(20))
+    assert DeepONetStep(net)(u1, u2, bc, pde) is None
+    net2 = _random_deeponet([3, 2, 1], [50, 2, 1], [2, 6, 1], 5, torch.nn.Identity, seed=4)
+    opt = torch.optim.AdamW(net2.parameters(), lr=0.01)
+    a = net2.train_step(opt, u1, u2, None, None, bc, pde)
+    assert net2._step.calls == 1
+    monkeypatch.setenv("PDEKAN_DISABLE_DEEPONET_STEP", "1")
+    net3 = _random_deeponet([3, 2, 1], [50, 2, 1], [2, 6, 1], 5, torch.nn.Identity, seed=4)
+    opt3 = torch.optim.AdamW(net3.parameters(), lr=0.01)
+    b = net3.train_step(opt3, u1, u2, None, None, bc, pde)
+    assert net3._step.calls == 0
+    assert max_rel(torch.stack(a).cpu(), torch.stack(b).cpu()) <= 2e-5
+    for p, q in zip(net2.parameters(), net3.parameters()):
+        assert max_rel(p.detach().cpu(), q.detach().cpu()) <= 2e-5
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", DEEPONET_CASES)
+def test_adamw_steps_follow_the_reference(golden, case, fused):
+    """Three AdamW(lr=0.01) steps of the loop body run1.py:217-233: the loss
+    trace and one updated tensor; as one library call per step and layer by layer."""
+    rec = golden(case)
+    net = build(rec)
+    net.fused = fused
     u1, u2, bc, pde = tensors(rec)
     opt = torch.optim.AdamW(net.parameters(), lr=0.01)
     trace = []
     for _ in range(len(rec["adamw_losses"])):
         loss, _, _ = net.train_step(opt, u1, u2, None, None, bc, pde)
         trace.append(loss.item())
+    assert (net._step is not None and net._step.calls == len(trace)) == fused
     assert max_rel(torch.tensor(trace), rec["adamw_losses64"]) <= 2e-5
     w = net.model5.layers[0].spline_weight
     assert max_rel(w.detach().cpu(), rec["adamw_final64.model5.layers.0.spline_weight"]) <= 2e-5
