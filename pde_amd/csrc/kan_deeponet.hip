@@ -12,17 +12,21 @@
 // The reference feeds model4 n copies of the row v and differentiates s with jacrev / hessian; B does not depend on
 // (x, t), so model4 runs on the one row and the derivatives of s are B times the input jets of the trunk.
 //
-//   don_sensor_forward_kernel   EP lanes per sensor row (one per edge): model1 and model2 forward, y1, y2, v to memory
-//   don_trunk_kernel            ONE block: first layer of model4 over the row v (thread = input feature, fixed-order
-//                               block sum), its upper layers on wave 0, then the trunk on every boundary and
-//                               collocation point with 4-jets (lane = (point, edge)), residual, losses, the trunk's
-//                               backward into a per-lane gradient table in LDS, the cotangent of B summed over the
-//                               points, the backward of model4's upper layers on wave 0; writes the trunk's and the
-//                               upper layers' gradients, the losses and the cotangent of model4's first-layer outputs
-//   don_sensor_backward_kernel  per sensor row: gradients of model4's first layer for that input feature (each
-//                               feature's weights belong to one row: no sums), the cotangent of v, then model1 and
+//   don_sensor_forward_kernel   EP lanes per sensor row (one per edge): model1 and model2 forward, y1, y2, v to memory,
+//                               and what v[r], as input feature r of model4's first layer, adds to that layer's outputs
+//   don_trunk_kernel            block = a share of the boundary and collocation points.  Every block first adds up
+//                               the outputs of model4's first layer (the features' shares, in a fixed order) and
+//                               runs model4's upper layers on wave 0 (B: the same bits in every block), then the
+//                               trunk on its points with 4-jets (lane = (point, edge)), residual, squared errors, the
+//                               trunk's backward into a per-lane gradient table in LDS; one partial per block: the
+//                               table's sums, the cotangent of B, the two sums of squares
+//   don_sensor_backward_kernel  every block first adds the trunk blocks' cotangents of B and takes them back through
+//                               model4's upper layers on wave 0 (block 0 writes those layers' gradients); then per
+//                               sensor row: gradients of model4's first layer for that input feature (each
+//                               feature's weights belong to one row: no sums), the cotangent of v, model1 and
 //                               model2 forward again and backward into per-lane tables; one partial per block
-//   don_sensor_finish_kernel    adds the blocks' partials in a fixed order and unpacks model1 / model2 gradients
+//   don_finish_kernel           adds the blocks' partials in a fixed order: model1 / model2 / trunk gradients
+//                               (unpacked), the three losses
 // Every sum has a fixed order: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -35,6 +39,8 @@ namespace pdekan {
 constexpr int kDonWidth = 8;                 // widest layer boundary of a network held in LDS
 constexpr int kDonBlocksMax = 1024;
 constexpr int kDonSensorThreads = 256;
+constexpr int kDonTrunkThreads = 256;
+constexpr int kDonTrunkBlocksMax = 64;
 
 struct DonLayer {
   int I, O, G, act;
@@ -71,11 +77,15 @@ __device__ __forceinline__ void don_stage(const DonNet& M, float* sW, float* sK,
     }
   }
 }
+// (thread 8 l + i takes input i of layer l: 32 threads per network, so callers hand each network its own 32)
 __device__ __forceinline__ void don_stage_spacing(const DonNet& M, float* sK, int tid) {
-  for (int l = 0; l < M.nl; ++l) {
+  const int i = tid & 7;
+#pragma unroll
+  for (int l = 0; l < kDonLayersMax; ++l) {
+    if (l >= M.nl || (tid >> 3) != l) continue;
     const DonLayer& L = M.L[l];
     const int nk = L.G + 7;
-    if (tid < L.I) sK[L.kofs + tid * (nk + 1) + nk] = equal_spacing_inv_h(sK + L.kofs + tid * (nk + 1), nk);
+    if (i < L.I) sK[L.kofs + i * (nk + 1) + nk] = equal_spacing_inv_h(sK + L.kofs + i * (nk + 1), nk);
   }
 }
 
@@ -209,8 +219,9 @@ __device__ __forceinline__ void don_unpack(const DonNet& M, const float* table, 
 // ---- sensors, forward: y1[r] = model1(u1[r]), y2[r] = model2(u2[r]), v[r] = y1[r] * y2[r]
 template <int EP>
 __global__ void __launch_bounds__(kDonSensorThreads)
-don_sensor_forward_kernel(DonNet M1, DonNet M2, const float* __restrict__ u1, const float* __restrict__ u2, int m,
-                          float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ v) {
+don_sensor_forward_kernel(DonLayer F, DonNet M1, DonNet M2, const float* __restrict__ u1, const float* __restrict__ u2,
+                          int m, float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ v,
+                          float* __restrict__ first_out) {
   constexpr int TB = kDonSensorThreads, PB = TB / EP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW1 = smem;
@@ -225,7 +236,7 @@ don_sensor_forward_kernel(DonNet M1, DonNet M2, const float* __restrict__ u1, co
   don_stage(M2, sW2, sK2, tid, TB);
   __syncthreads();
   don_stage_spacing(M1, sK1, tid);
-  don_stage_spacing(M2, sK2, tid);
+  don_stage_spacing(M2, sK2, tid - 32);
   __syncthreads();
   float* myA = sA + ps * slots;
   float* myC = sC + (tid - e) * 4;
@@ -244,18 +255,37 @@ don_sensor_forward_kernel(DonNet M1, DonNet M2, const float* __restrict__ u1, co
     const float a2 = myA[M2.slots - 4];
     DON_WAVE_SYNC();
     if (e == 0 && live) { y1[r] = a1; y2[r] = a2; v[r] = a1 * a2; }
+    // what input feature r of model4's first layer adds to each of its outputs: first_out[o][r]
+    if (e < F.O && live) {
+      const int C = F.G + 3, nk = F.G + 7;
+      const float x = a1 * a2;
+      Basis bs;
+      eval_basis<false>(F.grid + (size_t)r * nk, nk, x, bs);
+      const Act av = eval_act(F.act, x);
+      const size_t edge = (size_t)e * m + r;
+      const float sc = F.scaler ? F.scaler[edge] : 1.0f;
+      const float* w = F.spline_w + edge * C;
+      float s = av.f0 * F.base_w[edge];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = bs.c0 + k;
+        if (c >= 0 && c < C) s += (w[c] * sc) * bs.b[k];
+      }
+      first_out[edge] = s;
+    }
   }
 }
 
-// ---- the one block in the middle
-template <int EP, int TB>
-__global__ void __launch_bounds__(TB)
-don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, int m,
+// ---- the trunk: block = a share of the points
+template <int EP>
+__global__ void __launch_bounds__(kDonTrunkThreads)
+don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ first_out, int m,
                  const float* __restrict__ x_bc, const float* __restrict__ t_bc, const float* __restrict__ out_bc, int n_bc,
                  const float* __restrict__ x_pde, const float* __restrict__ t_pde, const float* __restrict__ out_pde,
-                 int n_pde, float sigma, float rate, float bc_weight, float* __restrict__ gy_first,
-                 float* __restrict__ losses, float* __restrict__ s_pred, float* __restrict__ res_out, int want_grads) {
-  constexpr int PB = TB / EP;
+                 int n_pde, float sigma, float rate, float bc_weight, float* __restrict__ y4_out,
+                 float* __restrict__ part5, float* __restrict__ part_b, float* __restrict__ part_l,
+                 float* __restrict__ s_pred, float* __restrict__ res_out, int want_grads) {
+  constexpr int TB = kDonTrunkThreads, PB = TB / EP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW5 = smem;
   float* sK5 = sW5 + round4(M5.P);
@@ -265,43 +295,24 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
   float* sG = sA + PB * M5.slots;            // [PB][8][4]
   float* sC = sG + PB * kDonWidth * 4;       // [TB][4]
   float* sA4 = sC + TB * 4;                  // wave 0's row through model4's upper layers
-  float* sG4 = sA4 + round4(M4.slots > 0 ? M4.slots : 4);
-  float* sC4 = sG4 + kDonWidth * 4;          // [64][4]
-  float* sT4 = sC4 + 64 * 4;                 // [trows of the upper layers][64]
-  float* sT = sT4 + M4.trows * 64;           // [max(trows of the trunk, 8)][TB]
-  __shared__ float sY4[kDonWidth], sB[kDonWidth], sGB[kDonWidth];
+  float* sC4 = sA4 + round4(M4.slots > 0 ? M4.slots : 4);   // [64][4]
+  float* sT = sC4 + 64 * 4;                  // [max(trows of the trunk, 8)][TB]
+  __shared__ float sY4[kDonWidth], sB[kDonWidth];
   __shared__ float sRed2[kDonWidth * 64];
   __shared__ float s_loss[TB / 64][2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int ps = tid / EP, e = tid % EP;
   don_stage(M5, sW5, sK5, tid, TB);
   don_stage(M4, sW4, sK4, tid, TB);
-  // ---- first layer of model4 on the row v: thread = input feature, its O outputs summed over the features
+  // ---- first layer of model4 on the row v: the features' shares of its O outputs, added in a fixed order
   {
-    const int C = F.G + 3, nk = F.G + 7;
     float acc[kDonWidth];
 #pragma unroll
     for (int o = 0; o < kDonWidth; ++o) acc[o] = 0.0f;
     for (int i = tid; i < m; i += TB) {
-      const float x = v[i];
-      Basis bs;
-      eval_basis<false>(F.grid + (size_t)i * nk, nk, x, bs);
-      const Act av = eval_act(F.act, x);
 #pragma unroll
-      for (int o = 0; o < kDonWidth; ++o) {
-        if (o < F.O) {
-          const size_t edge = (size_t)o * m + i;
-          const float sc = F.scaler ? F.scaler[edge] : 1.0f;
-          const float* w = F.spline_w + edge * C;
-          float s = av.f0 * F.base_w[edge];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = bs.c0 + k;
-            if (c >= 0 && c < C) s += (w[c] * sc) * bs.b[k];
-          }
-          acc[o] += s;
-        }
-      }
+      for (int o = 0; o < kDonWidth; ++o)
+        if (o < F.O) acc[o] += first_out[(size_t)o * m + i];
     }
 #pragma unroll
     for (int o = 0; o < kDonWidth; ++o)
@@ -309,7 +320,7 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
   }
   __syncthreads();
   don_stage_spacing(M5, sK5, tid);
-  don_stage_spacing(M4, sK4, tid);
+  don_stage_spacing(M4, sK4, tid - 32);
   for (int k = tid; k < F.O * 64; k += TB) {
     const int o = k >> 6, j = k & 63;
     float s = 0.0f;
@@ -321,11 +332,11 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
     float s = 0.0f;
     for (int j = 0; j < 64; ++j) s += sRed2[tid * 64 + j];
     sY4[tid] = s;
+    if (blockIdx.x == 0) y4_out[tid] = s;
   }
   {
     const int rows = M5.trows > kDonWidth ? M5.trows : kDonWidth;
     for (int k = tid; k < rows * TB; k += TB) sT[k] = 0.0f;
-    for (int k = tid; k < M4.trows * 64; k += TB) sT4[k] = 0.0f;
   }
   __syncthreads();
   // ---- upper layers of model4 on wave 0: B
@@ -341,7 +352,7 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
     }
   }
   __syncthreads();
-  // ---- the trunk on the boundary points, then on the collocation points
+  // ---- the trunk on this block's share of the boundary points and the collocation points
   float* myA = sA + ps * M5.slots;
   float* myG = sG + ps * kDonWidth * 4;
   float* myC = sC + (tid - e) * 4;
@@ -351,7 +362,7 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
   const float inv_bc = 1.0f / (float)n_bc, inv_pde = 1.0f / (float)n_pde;
   float loss_bc = 0.0f, loss_pde = 0.0f, gB = 0.0f;
   const int n_all = n_bc + n_pde;
-  for (int q0 = 0; q0 < n_all; q0 += PB) {
+  for (int q0 = blockIdx.x * PB; q0 < n_all; q0 += gridDim.x * PB) {
     const int q = q0 + ps;
     const bool live = q < n_all;
     const int qq = live ? q : n_all - 1;
@@ -402,83 +413,98 @@ don_trunk_kernel(DonLayer F, DonNet M4, DonNet M5, const float* __restrict__ v, 
     don_backward<TB>(M5, sW5, sK5, myA, myG, myC, myT, e, false);
     DON_WAVE_SYNC();
   }
-  // ---- losses
+  // ---- the block's partial: sums of squares, cotangent of B (the points' shares in order), the table's sums
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     loss_bc += __shfl_xor(loss_bc, d);
     loss_pde += __shfl_xor(loss_pde, d);
   }
   if (lane == 0) { s_loss[tid >> 6][0] = loss_bc; s_loss[tid >> 6][1] = loss_pde; }
-  __syncthreads();                            // (also: every lane's table column and sC reads are done)
-  if (tid == 0 && losses) {
+  __syncthreads();                            // (every wave is done with the contribution words and its table column)
+  if (tid == 0) {
     float b = 0.0f, p = 0.0f;
     for (int k = 0; k < TB / 64; ++k) { b += s_loss[k][0]; p += s_loss[k][1]; }
-    b *= inv_bc; p *= inv_pde;
-    losses[0] = p + bc_weight * b;
-    losses[1] = p;
-    losses[2] = b;
+    part_l[blockIdx.x * 2 + 0] = b;
+    part_l[blockIdx.x * 2 + 1] = p;
   }
   if (!want_grads) return;
-  sC[tid] = (e < n_out) ? gB : 0.0f;          // the cotangent of B: the points' shares, added in order
+  sC[tid] = (e < n_out) ? gB : 0.0f;
   __syncthreads();
   if (tid < n_out) {
     float s = 0.0f;
     for (int k = 0; k < PB; ++k) s += sC[k * EP + tid];
-    sGB[tid] = s;
+    part_b[blockIdx.x * kDonWidth + tid] = s;
   }
-  __syncthreads();
-  // ---- the trunk's gradients: the columns of the lanes that hold the same edge, added in order (into the first)
+  float* dst = part5 + (size_t)blockIdx.x * M5.P;
   for (int k = tid; k < M5.P; k += TB) {
     const DonLayer& L = M5.L[don_layer_of(M5, k)];
     const int C1 = L.G + 4;
     const int edge = (k - L.wofs) / C1, c = (k - L.wofs) - edge * C1;
-    float* row = sT + (size_t)(L.tofs + c) * TB + edge;
+    const float* row = sT + (size_t)(L.tofs + c) * TB + edge;
     float sum = 0.0f;
-#pragma unroll 8
+#pragma unroll
     for (int q = 0; q < PB; ++q) sum += row[q * EP];
-    row[0] = sum;
+    dst[k] = sum;
   }
-  __syncthreads();
-  don_unpack<TB>(M5, sT, tid, TB);
-  if (tid >= 64) return;
-  // ---- backward of model4's upper layers on wave 0: their gradients and the cotangent of the first layer's outputs
-  if (M4.nl == 0) {
-    if (tid < n_out) gy_first[tid] = sGB[tid];
-    return;
-  }
-  if (tid < n_out) *reinterpret_cast<float4*>(sG4 + tid * 4) = make_float4(sGB[tid], 0.f, 0.f, 0.f);
-  DON_WAVE_SYNC();
-  don_backward<64>(M4, sW4, sK4, sA4, sG4, sC4, sT4 + tid, tid, true);
-  if (tid < F.O) gy_first[tid] = sG4[tid * 4];
-  DON_WAVE_SYNC();
-  don_unpack<64>(M4, sT4, tid, 64);           // (one row: a lane's column is the sum)
 }
 
 // ---- sensors, backward
 template <int EP>
 __global__ void __launch_bounds__(kDonSensorThreads)
-don_sensor_backward_kernel(DonLayer F, DonNet M1, DonNet M2, const float* __restrict__ u1, const float* __restrict__ u2,
-                           int m, const float* __restrict__ y1, const float* __restrict__ y2,
-                           const float* __restrict__ v, const float* __restrict__ gy_first, float* __restrict__ part) {
+don_sensor_backward_kernel(DonLayer F, DonNet M1, DonNet M2, DonNet M4, const float* __restrict__ u1,
+                           const float* __restrict__ u2, int m, const float* __restrict__ y1,
+                           const float* __restrict__ y2, const float* __restrict__ v, const float* __restrict__ y4,
+                           const float* __restrict__ part_b, int trunk_blocks, int n_out, float* __restrict__ part) {
   constexpr int TB = kDonSensorThreads, PB = TB / EP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW1 = smem;
   float* sK1 = sW1 + round4(M1.P);
   float* sW2 = sK1 + round4(M1.kwords);
   float* sK2 = sW2 + round4(M2.P);
-  float* sA = sK2 + round4(M2.kwords);
+  float* sW4 = sK2 + round4(M2.kwords);
+  float* sK4 = sW4 + round4(M4.P);
+  float* sA = sK4 + round4(M4.kwords);
   const int slots = M1.slots > M2.slots ? M1.slots : M2.slots;
   float* sG = sA + PB * slots;
   float* sC = sG + PB * kDonWidth * 4;
-  float* sT1 = sC + TB * 4;                  // [trows of model1][TB], then [trows of model2][TB]
+  float* sA4 = sC + TB * 4;                  // wave 0's row through model4's upper layers
+  float* sG4 = sA4 + round4(M4.slots > 0 ? M4.slots : 4);
+  float* sC4 = sG4 + kDonWidth * 4;          // [64][4]
+  float* sT4 = sC4 + 64 * 4;                 // [trows of model4's upper layers][64]
+  float* sT1 = sT4 + M4.trows * 64;          // [trows of model1][TB], then [trows of model2][TB]
   float* sT2 = sT1 + M1.trows * TB;
+  __shared__ float sGY[kDonWidth];           // cotangent of the outputs of model4's first layer
   const int tid = threadIdx.x, ps = tid / EP, e = tid % EP;
   don_stage(M1, sW1, sK1, tid, TB);
   don_stage(M2, sW2, sK2, tid, TB);
-  for (int k = tid; k < (M1.trows + M2.trows) * TB; k += TB) sT1[k] = 0.0f;
+  don_stage(M4, sW4, sK4, tid, TB);
+  for (int k = tid; k < M4.trows * 64 + (M1.trows + M2.trows) * TB; k += TB) sT4[k] = 0.0f;
   __syncthreads();
   don_stage_spacing(M1, sK1, tid);
-  don_stage_spacing(M2, sK2, tid);
+  don_stage_spacing(M2, sK2, tid - 32);
+  don_stage_spacing(M4, sK4, tid - 64);
+  __syncthreads();
+  // ---- cotangent of B (the trunk blocks' shares, in order) back through model4's upper layers, on wave 0
+  if (tid < 64) {
+    float gb = 0.0f;
+    if (tid < n_out)
+      for (int b = 0; b < trunk_blocks; ++b) gb += part_b[b * kDonWidth + tid];
+    if (M4.nl == 0) {
+      if (tid < n_out) sGY[tid] = gb;
+    } else {
+      if (tid < F.O) *reinterpret_cast<float4*>(sA4 + tid * 4) = make_float4(y4[tid], 0.f, 0.f, 0.f);
+      DON_WAVE_SYNC();
+      don_forward(M4, sW4, sK4, sA4, sC4, tid);
+      if (tid < n_out) *reinterpret_cast<float4*>(sG4 + tid * 4) = make_float4(gb, 0.f, 0.f, 0.f);
+      DON_WAVE_SYNC();
+      don_backward<64>(M4, sW4, sK4, sA4, sG4, sC4, sT4 + tid, tid, true);
+      if (tid < F.O) sGY[tid] = sG4[tid * 4];
+      if (blockIdx.x == 0) {                  // (one row: a lane's column is the sum)
+        DON_WAVE_SYNC();
+        don_unpack<64>(M4, sT4, tid, 64);
+      }
+    }
+  }
   __syncthreads();
   float* myA = sA + ps * slots;
   float* myG = sG + ps * kDonWidth * 4;
@@ -497,7 +523,7 @@ don_sensor_backward_kernel(DonLayer F, DonNet M1, DonNet M2, const float* __rest
       const size_t edge = (size_t)e * m + rr;
       const float sc = F.scaler ? F.scaler[edge] : 1.0f;
       const float* w = F.spline_w + edge * C;
-      const float gy = gy_first[e];
+      const float gy = sGY[e];
       float gs = 0.0f, dphi = av.f1 * F.base_w[edge];
       if (live)                               // columns whose basis is zero at x
         for (int c = 0; c < C; ++c)
@@ -554,42 +580,64 @@ don_sensor_backward_kernel(DonLayer F, DonNet M1, DonNet M2, const float* __rest
   sums(M2, sT2, dst + M1.P);
 }
 
-// block = one edge of model1 or model2, thread = (column c = tid & 31, slice s = tid >> 5): slice s adds the partials
-// of blocks s, s + 8, ..., column c then adds its 8 slices in order, and the edge is unpacked
+// block = one edge of model1, model2 or the trunk, thread = (column c = tid & 31, slice s = tid >> 5): slice s adds the
+// partials of blocks s, s + 8, ..., column c then adds its 8 slices in order, and the edge is unpacked; the last
+// block adds the trunk blocks' sums of squares into the three losses.  first_block: the block index of block 0
+// (loss only: the last block alone)
 __global__ void __launch_bounds__(256)
-don_sensor_finish_kernel(DonNet M1, DonNet M2, const float* __restrict__ part, int nblocks) {
+don_finish_kernel(DonNet M1, DonNet M2, DonNet M5, const float* __restrict__ part, int sensor_blocks,
+                  const float* __restrict__ part5, const float* __restrict__ part_l, int trunk_blocks, float inv_bc,
+                  float inv_pde, float bc_weight, float* __restrict__ losses, int first_block) {
   __shared__ float s_sl[8][33];
   __shared__ float s_col[32];
   const int tid = threadIdx.x, c = tid & 31, sl = tid >> 5;
-  const size_t stride = (size_t)M1.P + M2.P;
-  const bool first = (int)blockIdx.x < M1.edges;
-  const DonNet& M = first ? M1 : M2;
-  int l = 0, edge = first ? blockIdx.x : blockIdx.x - M1.edges;
-  while (l + 1 < M.nl && edge >= M.L[l].O * M.L[l].I) { edge -= M.L[l].O * M.L[l].I; ++l; }
-  const DonLayer& L = M.L[l];
-  const int C = L.G + 3, C1 = C + 1;
-  const bool col = c < C1;
-  float v = 0.0f;
-  if (col) {
-    const float* src = part + (first ? 0 : M1.P) + L.wofs + edge * C1 + c;
-    for (int b = sl; b < nblocks; b += 8) v += src[(size_t)b * stride];
-  }
-  s_sl[sl][c] = v;
-  __syncthreads();
-  if (tid < 32) {
-    float gw = 0.0f;
-    for (int k = 0; k < 8; ++k) gw += s_sl[k][tid];
-    s_col[tid] = (col && c < C) ? gw * L.spline_w[(size_t)edge * C + c] : 0.0f;
+  const int blk = blockIdx.x + first_block;
+  auto edge_block = [&](const DonNet& M, int edge, const float* src0, size_t stride, int nblocks) {
+    int l = 0;
+    while (l + 1 < M.nl && edge >= M.L[l].O * M.L[l].I) { edge -= M.L[l].O * M.L[l].I; ++l; }
+    const DonLayer& L = M.L[l];
+    const int C = L.G + 3, C1 = C + 1;
+    const bool col = c < C1;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // (four loads in flight: every one is a trip to memory)
     if (col) {
-      if (c < C) L.g_spline[(size_t)edge * C + c] = gw * (L.scaler ? L.scaler[edge] : 1.0f);
-      else L.g_base[edge] = gw;
+      const float* src = src0 + L.wofs + edge * C1 + c;
+      for (int b0 = sl; b0 < nblocks; b0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = b0 + 8 * u;
+          if (b < nblocks) v[u] += src[(size_t)b * stride];
+        }
+      }
     }
-  }
-  __syncthreads();
-  if (tid == 0 && L.scaler && L.g_scaler) {
-    float gs = 0.0f;
-    for (int k = 0; k < C; ++k) gs += s_col[k];
-    L.g_scaler[edge] = gs;
+    s_sl[sl][c] = (v[0] + v[1]) + (v[2] + v[3]);
+    __syncthreads();
+    if (tid < 32) {
+      float gw = 0.0f;
+      for (int k = 0; k < 8; ++k) gw += s_sl[k][tid];
+      s_col[tid] = (col && c < C) ? gw * L.spline_w[(size_t)edge * C + c] : 0.0f;
+      if (col) {
+        if (c < C) L.g_spline[(size_t)edge * C + c] = gw * (L.scaler ? L.scaler[edge] : 1.0f);
+        else L.g_base[edge] = gw;
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && L.scaler && L.g_scaler) {
+      float gs = 0.0f;
+      for (int k = 0; k < C; ++k) gs += s_col[k];
+      L.g_scaler[edge] = gs;
+    }
+  };
+  const size_t stride_s = (size_t)M1.P + M2.P;
+  if (blk < M1.edges) edge_block(M1, blk, part, stride_s, sensor_blocks);
+  else if (blk < M1.edges + M2.edges) edge_block(M2, blk - M1.edges, part + M1.P, stride_s, sensor_blocks);
+  else if (blk < M1.edges + M2.edges + M5.edges) edge_block(M5, blk - M1.edges - M2.edges, part5, (size_t)M5.P, trunk_blocks);
+  else if (tid == 0 && losses) {
+    float b = 0.0f, p = 0.0f;
+    for (int k = 0; k < trunk_blocks; ++k) { b += part_l[k * 2]; p += part_l[k * 2 + 1]; }
+    b *= inv_bc; p *= inv_pde;
+    losses[0] = p + bc_weight * b;
+    losses[1] = p;
+    losses[2] = b;
   }
 }
 
@@ -641,7 +689,7 @@ static int r4(int v) { return (v + 3) & ~3; }
 struct DonPlan {
   DonLayer F;                                // first layer of model4
   DonNet M1, M2, M4, M5;                     // model1, model2, upper layers of model4, trunk
-  int ep_s, ep_t, tb_t, blocks_s;
+  int ep_s, ep_t, blocks_s, blocks_t;
   size_t lds_fwd, lds_bwd, lds_trunk;
 };
 
@@ -677,22 +725,22 @@ static const char* don_plan(const DonNetView nets[4], int64_t m, int64_t n_bc, i
   const int pbs = kDonSensorThreads / Z.ep_s;
   const int slots_s = Z.M1.slots > Z.M2.slots ? Z.M1.slots : Z.M2.slots;
   const size_t stage_s = (size_t)r4(Z.M1.P) + r4(Z.M1.kwords) + r4(Z.M2.P) + r4(Z.M2.kwords);
+  const size_t stage_4 = (size_t)r4(Z.M4.P) + r4(Z.M4.kwords);
+  const size_t row_4 = (size_t)r4(Z.M4.slots > 0 ? Z.M4.slots : 4);
   Z.lds_fwd = (stage_s + (size_t)pbs * slots_s + (size_t)kDonSensorThreads * 4) * sizeof(float);
-  Z.lds_bwd = (stage_s + (size_t)pbs * slots_s + (size_t)pbs * kDonWidth * 4 + (size_t)kDonSensorThreads * 4 +
+  Z.lds_bwd = (stage_s + stage_4 + (size_t)pbs * slots_s + (size_t)pbs * kDonWidth * 4 + (size_t)kDonSensorThreads * 4 +
+               row_4 + kDonWidth * 4 + 64 * 4 + (size_t)Z.M4.trows * 64 +
                (size_t)(Z.M1.trows + Z.M2.trows) * kDonSensorThreads) * sizeof(float);
-  if (Z.lds_bwd > 150 * 1024) return "model1 / model2 tables exceed the LDS of a CU";
+  if (Z.lds_bwd > 150 * 1024) return "model1 / model2 / model4 tables exceed the LDS of a CU";
   int64_t b = (m + pbs - 1) / pbs;
   Z.blocks_s = (int)(b > kDonBlocksMax ? kDonBlocksMax : b);
-  Z.tb_t = 0;
-  for (int tb : {1024, 256}) {
-    const int pb = tb / Z.ep_t;
-    const int rows = Z.M5.trows > kDonWidth ? Z.M5.trows : kDonWidth;
-    const size_t words = (size_t)r4(Z.M5.P) + r4(Z.M5.kwords) + r4(Z.M4.P) + r4(Z.M4.kwords) + (size_t)pb * Z.M5.slots +
-                         (size_t)pb * kDonWidth * 4 + (size_t)tb * 4 + r4(Z.M4.slots > 0 ? Z.M4.slots : 4) + kDonWidth * 4 +
-                         64 * 4 + (size_t)Z.M4.trows * 64 + (size_t)rows * tb;
-    if (words * sizeof(float) <= 140 * 1024) { Z.tb_t = tb; Z.lds_trunk = words * sizeof(float); break; }
-  }
-  if (!Z.tb_t) return "the trunk's tables exceed the LDS of a CU";
+  const int pbt = kDonTrunkThreads / Z.ep_t;
+  const int rows = Z.M5.trows > kDonWidth ? Z.M5.trows : kDonWidth;
+  Z.lds_trunk = ((size_t)r4(Z.M5.P) + r4(Z.M5.kwords) + stage_4 + (size_t)pbt * Z.M5.slots + (size_t)pbt * kDonWidth * 4 +
+                 (size_t)kDonTrunkThreads * 4 + row_4 + 64 * 4 + (size_t)rows * kDonTrunkThreads) * sizeof(float);
+  if (Z.lds_trunk > 150 * 1024) return "the trunk's tables exceed the LDS of a CU";
+  b = (n_bc + n_pde + pbt - 1) / pbt;
+  Z.blocks_t = (int)(b > kDonTrunkBlocksMax ? kDonTrunkBlocksMax : b);
   return nullptr;
 }
 
@@ -701,12 +749,15 @@ const char* deeponet_step_refusal(const DonNetView nets[4], int64_t m, int64_t n
   return don_plan(nets, m, n_bc, n_pde, Z);
 }
 
-// y1, y2, v [m] and the cotangent of model4's first-layer outputs (each on its own 256 bytes), then the blocks' partials
+// y1, y2, v [m], the outputs of model4's first layer, the features' shares of those outputs [O][m], then the partials
+// of the sensor blocks and of the trunk blocks (gradient sums, cotangent of B, sums of squares); each on its own 256 bytes
 static size_t don_align(size_t floats) { return (floats + 63) / 64 * 64; }
 size_t deeponet_step_ws_floats(const DonNetView nets[4], int64_t m, int64_t n_bc, int64_t n_pde) {
   DonPlan Z;
   if (don_plan(nets, m, n_bc, n_pde, Z)) return 0;
-  return 3 * don_align((size_t)m) + don_align(kDonWidth) + don_align((size_t)Z.blocks_s * (Z.M1.P + Z.M2.P));
+  return 3 * don_align((size_t)m) + don_align(kDonWidth) + don_align((size_t)Z.F.O * m) +
+         don_align((size_t)Z.blocks_s * (Z.M1.P + Z.M2.P)) + don_align((size_t)Z.blocks_t * Z.M5.P) +
+         don_align((size_t)Z.blocks_t * kDonWidth) + don_align((size_t)Z.blocks_t * 2);
 }
 
 bool launch_deeponet_step(const DonNetView nets[4], const float* u1, const float* u2, int64_t m, const float* x_bc,
@@ -718,32 +769,41 @@ bool launch_deeponet_step(const DonNetView nets[4], const float* u1, const float
   float* y1 = ws;
   float* y2 = y1 + don_align((size_t)m);
   float* v = y2 + don_align((size_t)m);
-  float* gy_first = v + don_align((size_t)m);
-  float* part = gy_first + don_align(kDonWidth);
+  float* y4 = v + don_align((size_t)m);
+  float* first_out = y4 + don_align(kDonWidth);
+  float* part = first_out + don_align((size_t)Z.F.O * m);
+  float* part5 = part + don_align((size_t)Z.blocks_s * (Z.M1.P + Z.M2.P));
+  float* part_b = part5 + don_align((size_t)Z.blocks_t * Z.M5.P);
+  float* part_l = part_b + don_align((size_t)Z.blocks_t * kDonWidth);
   const int want = nets[0].grads ? 1 : 0;
+  const int n_out = Z.M5.L[Z.M5.nl - 1].O;
   auto sensors_fwd = [&](auto kern) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Z.lds_fwd);
-    kern<<<Z.blocks_s, kDonSensorThreads, Z.lds_fwd, st>>>(Z.M1, Z.M2, u1, u2, (int)m, y1, y2, v);
+    kern<<<Z.blocks_s, kDonSensorThreads, Z.lds_fwd, st>>>(Z.F, Z.M1, Z.M2, u1, u2, (int)m, y1, y2, v, first_out);
   };
   if (Z.ep_s == 16) sensors_fwd(don_sensor_forward_kernel<16>);
   else sensors_fwd(don_sensor_forward_kernel<64>);
   auto trunk = [&](auto kern) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Z.lds_trunk);
-    kern<<<1, Z.tb_t, Z.lds_trunk, st>>>(Z.F, Z.M4, Z.M5, v, (int)m, x_bc, t_bc, out_bc, (int)n_bc, x_pde, t_pde, out_pde,
-                                          (int)n_pde, sigma, rate, bc_weight, gy_first, losses, s_pred, res_out, want);
+    kern<<<Z.blocks_t, kDonTrunkThreads, Z.lds_trunk, st>>>(Z.F, Z.M4, Z.M5, first_out, (int)m, x_bc, t_bc, out_bc, (int)n_bc,
+                                                             x_pde, t_pde, out_pde, (int)n_pde, sigma, rate, bc_weight, y4,
+                                                             part5, part_b, part_l, s_pred, res_out, want);
   };
-  if (Z.ep_t == 16 && Z.tb_t == 1024) trunk(don_trunk_kernel<16, 1024>);
-  else if (Z.ep_t == 16) trunk(don_trunk_kernel<16, 256>);
-  else if (Z.tb_t == 1024) trunk(don_trunk_kernel<64, 1024>);
-  else trunk(don_trunk_kernel<64, 256>);
-  if (!want) return true;
-  auto sensors_bwd = [&](auto kern) {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Z.lds_bwd);
-    kern<<<Z.blocks_s, kDonSensorThreads, Z.lds_bwd, st>>>(Z.F, Z.M1, Z.M2, u1, u2, (int)m, y1, y2, v, gy_first, part);
-  };
-  if (Z.ep_s == 16) sensors_bwd(don_sensor_backward_kernel<16>);
-  else sensors_bwd(don_sensor_backward_kernel<64>);
-  don_sensor_finish_kernel<<<Z.M1.edges + Z.M2.edges, 256, 0, st>>>(Z.M1, Z.M2, part, Z.blocks_s);
+  if (Z.ep_t == 16) trunk(don_trunk_kernel<16>);
+  else trunk(don_trunk_kernel<64>);
+  const int edges = Z.M1.edges + Z.M2.edges + Z.M5.edges;
+  const float inv_bc = 1.0f / (float)n_bc, inv_pde = 1.0f / (float)n_pde;
+  if (want) {
+    auto sensors_bwd = [&](auto kern) {
+      ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Z.lds_bwd);
+      kern<<<Z.blocks_s, kDonSensorThreads, Z.lds_bwd, st>>>(Z.F, Z.M1, Z.M2, Z.M4, u1, u2, (int)m, y1, y2, v, y4, part_b,
+                                                              Z.blocks_t, n_out, part);
+    };
+    if (Z.ep_s == 16) sensors_bwd(don_sensor_backward_kernel<16>);
+    else sensors_bwd(don_sensor_backward_kernel<64>);
+  }
+  don_finish_kernel<<<want ? edges + 1 : 1, 256, 0, st>>>(Z.M1, Z.M2, Z.M5, part, Z.blocks_s, part5, part_l, Z.blocks_t,
+                                                           inv_bc, inv_pde, bc_weight, losses, want ? 0 : edges);
   return true;
 }
 
