@@ -231,3 +231,50 @@ def test_trained_pinn_prices_the_call():
     ti = np.rint((1.0 - out["tau"]) * M).astype(int)           # row i = time level; time to expiry = 1 - i/M
     si = np.rint(out["S"] / (3.0 * K) * M).astype(int)
     assert np.sqrt(np.mean((out["pred"] - f[ti, si]) ** 2)) < 2e-2
+
+
+@pytest.mark.parametrize("widths12,widths4,widths5,m,n_bc,n_pde", [
+    ([3, 2, 1], [3000, 2, 1], [2, 6, 1], 3000, 100, 100),
+    ([3, 8, 8, 1], [37, 8, 8], [2, 8, 8, 8], 37, 1030, 3),          # more trunk blocks than the cap of 64
+])
+def test_one_call_step_stays_inside_its_workspace(widths12, widths4, widths5, m, n_bc, n_pde):
+    """pdekan_deeponet_step given exactly pdekan_deeponet_workspace_bytes() inside a larger allocation whose
+    remainder holds a pattern: the remainder survives, the numbers equal the ordinary call's, less is refused;
+    without gradient pointers the call writes the losses only."""
+    from pde_amd import _lib, functional as K
+    from pde_amd.deeponet import DeepONetStep
+    lib = _lib.load()
+    net = _random_deeponet(widths12, widths4, widths5, 5, torch.nn.Identity, seed=m)
+    g = torch.Generator().manual_seed(m)
+    r = lambda *shape: torch.rand(*shape, generator=g).cuda()
+    u1, u2 = r(m, 3), r(m, 3)
+    bc, pde = (r(n_bc), r(n_bc), r(n_bc)), (r(n_pde), r(n_pde), r(n_pde))
+    step = DeepONetStep(net)
+    assert step(u1, u2, bc, pde) is not None
+    loss0, grad0 = step.losses.clone(), step.flat_grad.clone()
+    nets = step._structs()
+    need = lib.pdekan_deeponet_workspace_bytes(nets, m, n_bc, n_pde)
+    assert need > 0
+    guard = 1 << 16
+    buf = torch.empty(need + guard, dtype=torch.uint8, device="cuda")
+    buf[need:] = 0xA5
+    step.flat_grad.zero_()
+    step.losses.zero_()
+    args = (K._ptr(u1), K._ptr(u2), m, K._ptr(bc[0]), K._ptr(bc[1]), K._ptr(bc[2]), n_bc, K._ptr(pde[0]), K._ptr(pde[1]),
+            K._ptr(pde[2]), n_pde, net.sigma, net.rate, net.bc_weight, K._ptr(step.losses), None, None)
+    _lib.check(lib.pdekan_deeponet_step(nets, *args, K._ptr(buf), need, K._stream(u1.device)))
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0xA5).all()), "a kernel wrote past the end of the workspace"
+    assert torch.equal(step.losses, loss0) and torch.equal(step.flat_grad, grad0)
+    assert lib.pdekan_deeponet_step(nets, *args, K._ptr(buf), need - 257, K._stream(u1.device)) == -2
+    # losses only
+    for k in range(4):
+        nets[k].grads = None
+    step.flat_grad.fill_(7.0)
+    step.losses.zero_()
+    _lib.check(lib.pdekan_deeponet_step(nets, *args, K._ptr(buf), need, K._stream(u1.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(step.losses, loss0) and bool((step.flat_grad == 7.0).all())
+    # a sensor count that is not model4's input width is refused with a message
+    assert lib.pdekan_deeponet_workspace_bytes(nets, m + 1, n_bc, n_pde) == 0
+    assert b"sensor" in lib.pdekan_last_error()
