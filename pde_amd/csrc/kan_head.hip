@@ -14,6 +14,7 @@
 // i is touched by lane i only (plain read-modify-write, no atomics, so the
 // result is bitwise reproducible); tables are added in wave order at the end.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kan_math.h"
 #include "kan_launch.h"
 #include "kan_wave.h"
@@ -216,6 +217,198 @@ head_bs_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t
   }
 }
 
+// The same for heads whose gradient table is too large to give every wave its own (256 inputs at grid 20: 32 KB a
+// table, three waves per compute unit with the kernel above): the I / 64 waves of a GROUP take 64 input features each
+// of the SAME point and share one table (a row is still touched by one lane only); a block holds as many groups as
+// tables fit beside the knot rows and the (unpadded) weight rows.  The output jet of a point is the sum of its
+// waves' sums, exchanged through LDS with one block barrier per point (partial jets double-buffered); every wave of
+// the group then knows the residual and pulls the cotangent back through its own features.  All waves of a block run
+// the same number of iterations (iters); points past the end contribute zeros.
+__host__ __device__ __forceinline__ int head_split_weight_words(int C1) { return C1 | 1; }
+// knot rows of that kernel: the first knot three more times in front, the last four more times behind (what
+// eval_basis_near_uniform reads without index clamps), then the feature's spacing word; an odd number of words
+__host__ __device__ __forceinline__ int head_split_knot_words(int nk) { return (nk + 8) | 1; }
+
+constexpr int kHeadSplitPoints = 3;          // points a group of waves works on per iteration
+
+template <int D, int D2, int ACT>
+__global__ void __launch_bounds__(768)
+head_bs_split_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t stride_n, int64_t stride_d,
+                     const float* __restrict__ target, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                     const float* __restrict__ wp, float sigma, float rate, float inv_n, float* __restrict__ res_out,
+                     float* __restrict__ ga, float* __restrict__ part, float* __restrict__ loss_part, int64_t N, int I,
+                     int G, unsigned* __restrict__ cot_out, int iters) {
+  constexpr int J = 1 + D + D2;
+  static_assert(D2 == D - 1, "assets first, time last");
+  static_assert(J == 4, "one float4 per jet");
+  const int nk = G + 2 * kOrder + 1, C = G + kOrder, C1 = C + 1, CP = head_row_words(C);
+  const int WR = head_split_weight_words(C1);
+  const int nw = blockDim.x >> 6, wpg = I >> 6, ng = nw / wpg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int kr = head_split_knot_words(nk);
+  const int tab = I * CP;
+  float* s_knots = reinterpret_cast<float*>(smem);        // [I][kr]: padded knot row, spacing word at nk + 7
+  float* s_w = s_knots + I * kr;                          // [I][WR]: spline columns, base column at C
+  float* s_acc = s_w + ((I * WR + 3) & ~3);               // [ng][I][CP]
+  float* s_y = s_acc + ng * tab;                          // [2][points per iteration][nw][4]
+  float* s_loss = s_y + 2 * kHeadSplitPoints * nw * 4;    // [nw]
+
+  for (int t = threadIdx.x; t < I * kr; t += blockDim.x) {
+    const int f = t / kr, k = t - f * kr;
+    const int kk = k < 3 ? 0 : (k - 3 < nk ? k - 3 : nk - 1);
+    s_knots[t] = (k < nk + 7) ? grid[(size_t)f * nk + kk] : ((k == nk + 7 && ginfo) ? ginfo[f] : 0.0f);
+  }
+  for (int t = threadIdx.x; t < I * WR; t += blockDim.x) {
+    const int i = t / WR, k = t - i * WR;
+    s_w[t] = (k < C1) ? wp[i * C1 + k] : 0.0f;
+  }
+  for (int t = threadIdx.x; t < ng * tab; t += blockDim.x) s_acc[t] = 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave / wpg, q = wave - grp * wpg;
+  const int i = q * 64 + lane;                            // the lane's input feature, for the whole kernel
+  const float hs2 = 0.5f * sigma * sigma;
+  float loss_local = 0.0f;
+  float gmax[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) gmax[j] = 0.f;
+  const float* krow = s_knots + i * kr + 3;               // knot 0
+  const float g0 = krow[0], glast = krow[nk - 1], invh = krow[nk + 4];
+  const float* wrow = s_w + i * WR;
+  const float wbase = wrow[C];
+  float* arow = s_acc + grp * tab + i * CP + 3;
+  const int joff = i * J;
+
+  // A group works on PP points per iteration (their chains of LDS round trips overlap; one block barrier for the
+  // PP of them); the loads of an iteration's points (jets, coordinates, targets) are issued one iteration ahead.
+  constexpr int PP = kHeadSplitPoints;
+  const int64_t pstride = (int64_t)gridDim.x * ng;
+  const int64_t pfirst = (int64_t)blockIdx.x * ng + grp;
+  struct Fetched { float4 jet; float xs[D2]; float tgt; };
+  auto fetch = [&](int64_t pp) {
+    const int64_t pc = pp < N ? pp : N - 1;
+    Fetched f;
+    f.jet = *reinterpret_cast<const float4*>(a + pc * I * J + joff);
+#pragma unroll
+    for (int d = 0; d < D2; ++d) f.xs[d] = x[pc * stride_n + d * stride_d];
+    f.tgt = target ? target[pc] : 0.0f;
+    return f;
+  };
+  Fetched nx[PP];
+#pragma unroll
+  for (int k = 0; k < PP; ++k) nx[k] = fetch(pfirst + k * pstride);
+
+  for (int it = 0; it < iters; ++it) {
+    int64_t p[PP];
+    bool valid[PP];
+    float jet[PP][J], xs[PP][D2], tgt[PP];
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      p[k] = pfirst + ((int64_t)it * PP + k) * pstride;
+      valid[k] = p[k] < N;
+      jet[k][0] = nx[k].jet.x; jet[k][1] = nx[k].jet.y; jet[k][2] = nx[k].jet.z; jet[k][3] = nx[k].jet.w;
+#pragma unroll
+      for (int d = 0; d < D2; ++d) xs[k][d] = nx[k].xs[d];
+      tgt[k] = nx[k].tgt;
+    }
+#pragma unroll
+    for (int k = 0; k < PP; ++k) nx[k] = fetch(p[k] + PP * pstride);
+    Basis bs[PP];
+    Act av[PP];
+    float p1[PP], p2[PP], p3[PP];
+    float* sy = s_y + (it & 1) * PP * nw * 4;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      if (invh > 0.0f) eval_basis_uniform_oneshot<true>(krow, nk, g0, glast, invh, jet[k][0], bs[k]);
+      else if (invh < 0.0f) eval_basis_near_uniform<true>(krow, nk, g0, glast, -invh, jet[k][0], bs[k]);
+      else eval_basis<true>(krow, nk, jet[k][0], bs[k]);
+      av[k] = eval_act(ACT, jet[k][0]);
+      float q0 = wbase * av[k].f0, q1 = wbase * av[k].f1, q2 = wbase * av[k].f2, q3 = wbase * av[k].f3;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = bs[k].c0 + m;
+        const bool in = c >= 0 && c < C;
+        const float wm = in ? wrow[in ? c : 0] : 0.0f;
+        q0 += wm * bs[k].b[m]; q1 += wm * bs[k].d1[m]; q2 += wm * bs[k].d2[m]; q3 += wm * bs[k].d3[m];
+      }
+      p1[k] = q1; p2[k] = q2; p3[k] = q3;
+      float y[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) y[j] = 0.0f;
+      jet_accumulate<D, D2>(y, jet[k], q0, q1, q2);
+      wave_sum4(y[0], y[1], y[2], y[3]);
+      if (lane == 0) *reinterpret_cast<float4*>(sy + (k * nw + wave) * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      float y[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) y[j] = 0.0f;
+      for (int w = 0; w < wpg; ++w) {                     // the group's waves, in order
+        const float4 v = *reinterpret_cast<const float4*>(sy + (k * nw + grp * wpg + w) * 4);
+        y[0] += v.x; y[1] += v.y; y[2] += v.z; y[3] += v.w;
+      }
+      float res = y[D] + rate * y[0];
+#pragma unroll
+      for (int d = 0; d < D2; ++d) res = res - hs2 * xs[k][d] * xs[k][d] * y[1 + D + d] - rate * xs[k][d] * y[1 + d];
+      const float diff = valid[k] ? res - tgt[k] : 0.0f;
+      if (q == 0) loss_local += diff * diff;
+      if (lane == 0 && q == 0 && valid[k] && res_out) res_out[p[k]] = res;
+      if (part || ga) {
+        const float g = 2.0f * diff * inv_n;
+        float gy[J];
+        gy[0] = g * rate;
+#pragma unroll
+        for (int d = 0; d < D2; ++d) { gy[1 + d] = -g * rate * xs[k][d]; gy[1 + D + d] = -g * hs2 * xs[k][d] * xs[k][d]; }
+        gy[D] = g;
+        float A0, A1, A2;
+        jet_pullback_coeffs<D, D2>(gy, jet[k], A0, A1, A2);
+        if (part) {                                       // (the PP points of a lane may share columns: in program order)
+          float* row = arow + bs[k].c0;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) row[m] += A0 * bs[k].b[m] + A1 * bs[k].d1[m] + A2 * bs[k].d2[m];
+          arow[C + 3] += A0 * av[k].f0 + A1 * av[k].f1 + A2 * av[k].f2;
+        }
+        if (ga && valid[k]) {
+          float out[J];
+          out[0] = A0 * p1[k] + A1 * p2[k] + A2 * p3[k];
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            float v = gy[1 + d] * p1[k];
+            if (d < D2) v += 2.0f * jet[k][1 + d] * gy[1 + D + d] * p2[k];
+            out[1 + d] = v;
+          }
+#pragma unroll
+          for (int d = 0; d < D2; ++d) out[1 + D + d] = gy[1 + D + d] * p1[k];
+          *reinterpret_cast<float4*>(ga + p[k] * I * J + joff) = make_float4(out[0], out[1], out[2], out[3]);
+#pragma unroll
+          for (int j = 0; j < J; ++j) absmax_into(gmax[j], out[j]);
+        }
+      }
+    }
+  }
+  if (cot_out && ga) publish_slot_absmax<J>(gmax, cot_out);
+  if (lane == 0) s_loss[wave] = loss_local;
+  __syncthreads();
+  if (part) {
+    float* dst = part + (size_t)blockIdx.x * I * C1;
+    for (int t = threadIdx.x; t < I * C1; t += blockDim.x) {
+      const int f = t / C1, c = t - f * C1;
+      const int src = f * CP + (c < C ? c + 3 : C + 6);
+      float s = 0.0f;
+      for (int w = 0; w < ng; ++w) s += s_acc[w * tab + src];
+      dst[t] = s;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int w = 0; w < nw; ++w) s += s_loss[w];
+    loss_part[blockIdx.x] = s;
+  }
+}
+
 static size_t head_table_bytes(const LayerView& L) { return (size_t)(L.I + 1) * head_row_words(L.C()) * 4; }
 
 constexpr size_t kLdsPerBlockMax = 160 * 1024;            // gfx950: 160 KiB per workgroup
@@ -231,6 +424,27 @@ static int head_waves(const LayerView& L) {
   return 1;
 }
 
+// groups of I / 64 waves that share a table (head_bs_split_kernel): as many as the LDS holds, 16 waves at most;
+// 0 = the layer stays on the table-per-wave kernel (heads of one asset + time whose tables leave it under 4 waves)
+constexpr size_t kHeadSplitWaveBytes = 2 * kHeadSplitPoints * 16 + 4;   // a wave's partial jets (double-buffered) and loss sum
+static size_t head_split_fixed_bytes(const LayerView& L) {
+  return (size_t)L.I * head_split_knot_words(L.nk()) * 4 + (((size_t)L.I * head_split_weight_words(L.C1()) + 3) & ~(size_t)3) * 4;
+}
+static int head_split_groups(int D, const LayerView& L) {
+  const char* off = getenv("PDEKAN_DISABLE_HEAD_SPLIT");
+  if ((off && off[0] == '1') || D != 2 || L.I < 128 || L.I % 64 != 0 || head_waves(L) >= 4) return 0;
+  const int wpg = L.I / 64;
+  const size_t table = (size_t)L.I * head_row_words(L.C()) * 4;
+  int ng = 0;
+  while ((ng + 1) * wpg <= 12 &&             // (768 threads: three waves per SIMD, 168 registers each)
+         head_split_fixed_bytes(L) + (size_t)(ng + 1) * table + (size_t)(ng + 1) * wpg * kHeadSplitWaveBytes + 64 <= kLdsPerBlockMax) ++ng;
+  return ng * wpg >= 8 ? ng : 0;              // (worth it from 8 waves per compute unit)
+}
+static size_t head_split_lds_bytes(const LayerView& L, int ng) {
+  const int nw = ng * (L.I / 64);
+  return head_split_fixed_bytes(L) + (size_t)ng * L.I * head_row_words(L.C()) * 4 + (size_t)nw * kHeadSplitWaveBytes;
+}
+
 // dynamic LDS of a block: knot rows (+ 1/h), the padded weight rows, one gradient table per wave, the waves' loss sums
 static size_t head_lds_bytes(const LayerView& L) {
   const int nw = head_waves(L);
@@ -244,6 +458,11 @@ bool head_eligible(int D, const LayerView& L) {
 }
 
 int head_blocks(int64_t N, const LayerView& L) {
+  if (const int ng = head_split_groups(2, L)) {            // (asked for heads of one asset + time only: see launch_head_bs)
+    int64_t b = (N + (int64_t)ng * 4 - 1) / ((int64_t)ng * 4);
+    if (b > 1024) b = 1024;                               // one block per compute unit at a time, four rounds
+    return (int)(b < 1 ? 1 : b);
+  }
   const int nw = head_waves(L);
   // at least 4 points per wave (small batches are latency-bound: more, shorter blocks finish sooner)
   int64_t b = (N + (int64_t)nw * 4 - 1) / ((int64_t)nw * 4);
@@ -285,6 +504,20 @@ static void head_dispatch(const LayerView& L, const float* a, const float* x, in
 void launch_head_bs(int D, const LayerView& L, const float* a, const float* x, int64_t sn, int64_t sd,
                     const float* target, const float* wp, float sigma, float rate, float inv_n, float* res,
                     float* ga, float* part, float* loss_part, int nblocks, int64_t N, hipStream_t st, unsigned* cot_out) {
+  if (const int ng = (D == 2) ? head_split_groups(D, L) : 0) {
+    const int nw = ng * (L.I / 64);
+    const size_t lds = head_split_lds_bytes(L, ng);
+    const int64_t per_iter = (int64_t)nblocks * ng * kHeadSplitPoints;
+    const int iters = (int)((N + per_iter - 1) / per_iter);
+    auto go = [&](auto k) {
+      ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+      k<<<nblocks, 64 * nw, lds, st>>>(a, x, sn, sd, target, L.grid, L.ginfo, wp, sigma, rate, inv_n, res, ga, part, loss_part,
+                                       N, L.I, L.G, cot_out, iters);
+    };
+    if (L.act == kActSiLU) go(head_bs_split_kernel<2, 1, kActSiLU>);
+    else go(head_bs_split_kernel<2, 1, kActIdentity>);
+    return;
+  }
   if (D == 2) head_dispatch<2, 1>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
   else head_dispatch<6, 5>(L, a, x, sn, sd, target, wp, sigma, rate, inv_n, res, ga, part, loss_part, nblocks, N, st, cot_out);
 }

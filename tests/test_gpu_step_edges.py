@@ -113,6 +113,34 @@ def test_heads_too_large_for_the_fused_kernel_take_the_separate_kernels(widths, 
     assert max_rel(step.flat_grad.cpu(), _flat(ref["grads"])) <= TOL
 
 
+@pytest.mark.parametrize("widths,G,N,act", [([2, 256, 1], 20, 1000, "silu"), ([2, 192, 1], 30, 37, "silu"),
+                                            ([2, 256, 1], 20, 5, "identity"), ([2, 64, 256, 1], 20, 4099, "silu")])
+def test_wide_heads_whose_waves_share_a_gradient_table(widths, G, N, act, monkeypatch):
+    """Heads whose gradient table is too large for one per wave (256 inputs at grid 20, 192 at grid 30): the waves
+    of a group take 64 features each of the same point and share a table.  Against the fp64 oracle and against
+    the table-per-wave kernel; ragged point counts leave groups idle in the last iteration."""
+    from pde_amd.pinn import BlackScholesStep
+    m = _random_model(widths, G, 21, act=torch.nn.SiLU if act == "silu" else torch.nn.Identity)
+    x = torch.rand(N, 2, generator=torch.Generator().manual_seed(22))
+    tgt = torch.rand(N, generator=torch.Generator().manual_seed(23))
+    ref = O.pinn_step(x.double(), O.layers_from_state_dict(m.state_dict(), dtype=torch.float64), act, target=tgt.double())
+    mg = m.cuda()
+    step = BlackScholesStep(mg)
+    res = torch.empty(N, device="cuda")
+    loss = step(x.cuda(), target=tgt.cuda(), residual_out=res).item()
+    assert max_rel(res.cpu(), ref["res"]) <= TOL
+    assert abs(loss - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    assert max_rel(step.flat_grad.cpu(), _flat(ref["grads"])) <= TOL
+    g_split, l_split = step.flat_grad.clone(), step.loss.clone()
+    step(x.cuda(), target=tgt.cuda())
+    assert torch.equal(step.flat_grad, g_split) and torch.equal(step.loss, l_split)      # same bits every time
+    monkeypatch.setenv("PDEKAN_DISABLE_HEAD_SPLIT", "1")
+    step2 = BlackScholesStep(mg)
+    step2(x.cuda(), target=tgt.cuda())
+    assert max_rel(step2.flat_grad.cpu(), g_split.cpu()) <= 2e-6
+    assert not torch.equal(step2.flat_grad, g_split)                # (another summation order: another kernel ran)
+
+
 @pytest.mark.parametrize("I,O_,G,N", [(2, 64, 10, 1000), (64, 64, 10, 777), (64, 1, 10, 500), (5, 3, 5, 100)])
 def test_layer_without_standalone_scaler(I, O_, G, N):
     """enable_standalone_scale_spline=False (kan.py:16, :145-151: the spline weight is used as it is; the ABI gets
