@@ -129,6 +129,43 @@ def test_one_call_step_agrees_with_the_layerwise_path(widths12, widths4, widths5
         assert max_rel(p.grad.cpu(), w.cpu()) <= 5e-5, (name, max_rel(p.grad.cpu(), w.cpu()))
 
 
+def test_one_call_step_without_standalone_scalers_and_on_moved_grids():
+    """Layers built with enable_standalone_scale_spline=False (kan.py:16: no spline_scaler parameter, the ABI gets
+    NULL) and knot rows moved off their equal spacing (what update_grid leaves): the one-call step against the
+    layer-by-layer path."""
+    from pde_amd.deeponet import DeepONetStep
+    from pde_amd.kan import KANLinear
+    net = _random_deeponet([3, 3, 1], [90, 3, 2], [2, 5, 2], 5, torch.nn.SiLU, seed=9)
+    for m in (net.model1, net.model2, net.model4, net.model5):   # (KAN's constructor has no switch for it, kan.py:240-252)
+        m.layers = torch.nn.ModuleList(
+            KANLinear(l.in_features, l.out_features, grid_size=5, base_activation=torch.nn.SiLU,
+                      enable_standalone_scale_spline=False, scale_spline=0.6) for l in m.layers)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(10)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.3 * torch.randn(p.shape, generator=g).cuda())
+    with torch.no_grad():
+        for m in (net.model1, net.model2, net.model4, net.model5):
+            for layer in m.layers:
+                layer.grid[:, 3:-3] += (0.12 * torch.rand(layer.grid[:, 3:-3].shape, generator=g) - 0.06).cuda()
+    r = lambda *shape: torch.rand(*shape, generator=g).cuda()
+    u1, u2 = r(90, 3) * 1.6 - 0.8, r(90, 3) * 1.6 - 0.8
+    bc, pde = (r(50) * 1.8 - 0.9, r(50) * 1.8 - 0.9, r(50)), (r(61) * 1.8 - 0.9, r(61) * 1.8 - 0.9, 0.1 * r(61))
+    bc_loss = net.loss_bcs(u1, u2, None, None, *bc)
+    pde_loss = net.loss_res(u1, u2, None, None, *pde)
+    (pde_loss + net.bc_weight * bc_loss).backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    assert not any("spline_scaler" in n for n, _ in net.named_parameters())
+    for p in net.parameters():
+        p.grad = None
+    losses = DeepONetStep(net)(u1, u2, bc, pde)
+    assert losses is not None
+    assert max_rel(losses[1:].cpu(), torch.stack([pde_loss, bc_loss]).detach().cpu()) <= 2e-5
+    for (name, p), w in zip(net.named_parameters(), want):
+        assert max_rel(p.grad.cpu(), w.cpu()) <= 5e-5, (name, max_rel(p.grad.cpu(), w.cpu()))
+
+
 def test_one_call_step_refuses_what_it_cannot_hold(monkeypatch):
     """Networks wider than the kernels hold, and the A/B switch: train_step then runs layer by layer, same numbers."""
     from pde_amd.deeponet import DeepONetStep
