@@ -113,7 +113,7 @@ def roofline_seconds(cost):
 
 HIP_KERNEL_OF = {"bwd_weight.mfma": "bwd_weight_mfma_kernel<", "bwd_weight.mfma_bf16x3": "bwd_weight_bf16x3_kernel<",
                  "bwd_weight.mfma_f16x2": "bwd_weight_f16", "bwd_input.sparse": "bwd_input_sparse_kernel<",
-                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": "fwd_f16_kernel<",
+                 "fwd.sparse": "fwd_sparse_kernel<64, 4,", "fwd.mfma_f16x2": ("fwd_f16_kernel<", "fwd_sp_f16_kernel<"),
                  "bwd_input.mfma_f16x2": "bwd_input_f16_kernel<", "head_fused": "head_bs_kernel<"}
 
 
@@ -140,6 +140,7 @@ def profiled_traffic(kname, name, n_local, J=4):
     hip = (HIP_KERNEL_OF_12.get(key) if J == 12 else None) or HIP_KERNEL_OF.get(key)
     if hip is None:
         return None, None
+    hips = hip if isinstance(hip, tuple) else (hip,)       # (a layer's kernel may be one of several templates)
     want = f"# workload={name} n_local={n_local} sources={sources_digest()}"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.txt")), reverse=True):
         with open(path) as f:
@@ -151,7 +152,7 @@ def profiled_traffic(kname, name, n_local, J=4):
         fetch = write = None
         best = {"FETCH_SIZE=": -1.0, "WRITE_SIZE=": -1.0}
         for line in lines:
-            if line.startswith(hip.split("<")[0]) and hip in line and "avg_ms=" in line:
+            if any(line.startswith(h.split("<")[0]) and h in line for h in hips) and "avg_ms=" in line:
                 avg = float(line.split("avg_ms=")[1].split()[0])
                 for tok in line.split():
                     for key in best:

@@ -317,7 +317,10 @@ struct BwiTiles {
 // WIDE (C1 = 14): the forward image is laid out for fwd12w_f16_kernel instead,
 //   wplf[O/64][I features][2 n][2 planes][64 lanes] x 16 bytes, lane (r = lane&31, h = lane>>5) holds output
 //   64*by + 32n + r, columns wide_col(h, 0 .. 7) of the feature (the same number of bytes)
-template <int C1, bool WIDE>
+// SPARSE (C1 = 14): the forward image is laid out for fwd_sp_f16_kernel (see there),
+//   wsp[O/64][I/4 stages][4 n][2 planes][2 halves][64 lanes] x 16 bytes, lane (oc = lane&15, tb = lane>>4) holds output
+//   64*by + 16n + oc; half h, element e: feature tb/2 + 2h of the stage, column 4*(e&3) + 2*(tb&1) + (e>>2)
+template <int C1, bool WIDE, bool SPARSE = false>
 __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsigned* __restrict__ wmax,
                                       u32x4* __restrict__ wplf, u32x4* __restrict__ wplb, int I, int O) {
   constexpr int CP = (C1 + 7) / 8 * 8, KS = CP / 8;
@@ -329,7 +332,19 @@ __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsign
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total_f + total_b; t += gridDim.x * blockDim.x) {
     float v[8];
     u32x4* dst;
-    if (WIDE && t < total_f) {
+    int lo_plane = 64;                      // where the low plane goes, in u32x4 behind the high plane
+    if (SPARSE && t < total_f) {
+      const int lane = t & 63, half = (t >> 6) & 1, n = (t >> 7) & 3, st = (t >> 9) % nst, by = (t >> 9) / nst;
+      const int o = by * 64 + n * 16 + (lane & 15), tb = lane >> 4;
+      const int f = st * 4 + (tb >> 1) + 2 * half;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 4 * (e & 3) + 2 * (tb & 1) + (e >> 2);
+        v[e] = (c < C1) ? wp[((size_t)o * I + f) * C1 + c] * sw : 0.0f;
+      }
+      dst = wplf + ((((size_t)(by * nst + st) * 4 + n) * 2) * 2 + half) * 64 + lane;
+      lo_plane = 128;
+    } else if (WIDE && t < total_f) {
       const int lane = t & 63, n = (t >> 6) & 1, f = (t >> 7) % I, by = (t >> 7) / I;
       const int o = by * 64 + n * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
@@ -369,7 +384,7 @@ __global__ void pack_wplanes16_kernel(const float* __restrict__ wp, const unsign
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_pair16(v[2 * e], v[2 * e + 1], h[e], l[e]);
     dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
-    dst[64] = (u32x4){l[0], l[1], l[2], l[3]};
+    dst[lo_plane] = (u32x4){l[0], l[1], l[2], l[3]};
   }
 }
 
@@ -638,6 +653,245 @@ fwd_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, cons
   const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
   if (cls == 1) fwd_f16_body<C1, ACT, false, LONGK>(a, grid, ginfo, wpl, y, N, I, O, amax_in, wmax, amax_out);
   else if (cls == 2) fwd_f16_body<C1, ACT, true, LONGK>(a, grid, ginfo, wpl, y, N, I, O, amax_in, wmax, amax_out);
+}
+
+// ==========================================================================================================
+// forward on the structured-sparsity matrix instruction.  Of the 16 padded columns of a feature a row of E holds 5
+// (the 4 live bases c0 .. c0+3 and the base-activation column 13).  Laid out as column c -> (group c % 4, slot c / 4)
+// the 4 live columns fall into 4 different groups of 4 and the base column into group 1: at most 2 non-zeros per
+// group of 4, which is what v_smfmac_f32_16x16x64_f16 takes as its A operand - 8 values per lane and row for 16
+// dense positions, each with a 2-bit position inside its group - at the price of a dense 16 x 16 x 32 instruction.
+// Half the matrix instructions, and NO E tile: a row tile is one jet of the wave's 16 points, lane (p, f) of the
+// expansion holds exactly the A operand of row p for feature f of the stage (K = 64 = 4 features x 16 positions), so
+// the operands go from the expansion's registers into the instruction (a byte permute puts jet j of two columns into
+// one word).  Operand layout of the instruction as measured on the hardware: A lane (row = lane & 15, ta = lane >> 4),
+// compressed element j -> pair g = j / 2 of 4 dense positions, which B holds in lane block 2 (ta & 1) + g / 2,
+// elements 8 (ta >> 1) + 4 (g & 1) + position; positions from bits 2j+1 : 2j of the index register.
+// B operands (pack_wplanes16_kernel<14, false, true>) stream from L2 one stage ahead; D: lane (output 16n + lane & 15)
+// holds points 4 (lane >> 4) .. + 3 of row tile (jet) j.
+// ==========================================================================================================
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+
+struct SpA { u32x4 h[4], l[4]; unsigned idx; };            // A operands of one stage: [jet], and the positions
+struct SpW { u32x4 h[2], l[2]; };                         // B operands of one (stage, output tile): [half]
+
+__device__ __forceinline__ f16x16 sp_b16(const u32x4& a, const u32x4& b) {
+  return __builtin_shufflevector(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10,
+                                 11, 12, 13, 14, 15);
+}
+
+// x in group order: out[g] = in[(g - r) & 3]
+__device__ __forceinline__ void sp_rotate(float (&x)[4], int r) {
+  const bool r1 = (r & 1) != 0, r2 = (r & 2) != 0;
+  const float a0 = r1 ? x[3] : x[0], a1 = r1 ? x[0] : x[1], a2 = r1 ? x[1] : x[2], a3 = r1 ? x[2] : x[3];
+  x[0] = r2 ? a2 : a0; x[1] = r2 ? a3 : a1; x[2] = r2 ? a0 : a2; x[3] = r2 ? a1 : a3;
+}
+
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ void sp_expand(const float* knots, int nk, f32x4 jet, const JetScales& sc, SpA& out) {
+  constexpr int C = C1 - 1;
+  const FeatGrid fg = {knots[0], knots[nk - 1], fabsf(knots[GEN ? nk + 4 : nk])};
+  Basis bs;
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
+  const Act av = eval_act(ACT, jet[0]);
+  // group g holds the live column c_g = 4 slot_g + g, slot_g = (c0 >> 2) + (g < (c0 & 3)); columns outside 0 .. C-1
+  // count for nothing (their positions may be another column's: zeroed here, not by zero weights)
+  const int r = bs.c0 & 3, base4 = bs.c0 >> 2;
+  sp_rotate(bs.b, r); sp_rotate(bs.d1, r); sp_rotate(bs.d2, r);
+  unsigned idx = 0xCCCCu;                                  // the second element of every pair: position 3
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int slot = base4 + (g < r ? 1 : 0);
+    const bool ok = slot >= 0 && 4 * slot + g < C;
+    bs.b[g] = ok ? bs.b[g] : 0.0f; bs.d1[g] = ok ? bs.d1[g] : 0.0f; bs.d2[g] = ok ? bs.d2[g] : 0.0f;
+    idx |= (unsigned)(slot & 3) << (4 * g);
+  }
+  out.idx = idx;
+  const float a1 = jet[1] * sc.s[1], a2 = jet[2] * sc.s[2], a3 = jet[3] * sc.s[3], q3 = jet[1] * jet[1] * sc.s[3];
+  // word g of jet j: the live column's jet j in the low half, the pair's second element in the high half (group 1: the
+  // base column, C = 4 * 3 + 1; the other groups: zero) - cut in that arrangement, so nothing is moved afterwards
+  static_assert(C == 13, "the base column sits in group 1, slot 3");
+  const f32x4 cb = {av.f0 * sc.s[0], av.f1 * a1, av.f1 * a2, av.f2 * q3 + av.f1 * a3};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 cg = {bs.b[g] * sc.s[0], bs.d1[g] * a1, bs.d1[g] * a2, bs.d2[g] * q3 + bs.d1[g] * a3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h, l;
+      if (g == 1) {
+        split_pair16(cg[j], cb[j], h, l);
+      } else {                                 // (x, 0): the high halves of both planes stay zero
+        asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(cg[j]));
+        l = 0u;
+        asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(cg[j]));
+      }
+      out.h[j][g] = h;
+      out.l[j][g] = l;
+    }
+  }
+}
+
+constexpr int kSpStageVecs = 4 * 2 * 2 * 64;               // u32x4 of W planes per stage and block of 64 outputs
+
+// output tile n of a stage's W planes
+__device__ __forceinline__ void sp_load_w(SpW& W, const u32x4* __restrict__ stage, int n, int lane) {
+  const u32x4* src = stage + n * 4 * 64 + lane;
+  W.h[0] = src[0]; W.h[1] = src[64]; W.l[0] = src[128]; W.l[1] = src[192];
+}
+
+// the 4 row tiles (jets) against output tile n: 12 matrix instructions on 4 accumulators
+__device__ __forceinline__ void sp_multiply(f32x4 (&acc)[4][4], const SpA& A, const SpW& W, int n) {
+  const f16x16 Bh = sp_b16(W.h[0], W.h[1]), Bl = sp_b16(W.l[0], W.l[1]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[j][n] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.l[j]), Bh, acc[j][n], (int)A.idx, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[j][n] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j]), Bl, acc[j][n], (int)A.idx, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[j][n] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j]), Bh, acc[j][n], (int)A.idx, 0, 0);
+}
+
+// One stage: the 4 output tiles are multiplied with the B tiles in Wr; as soon as the matrix instructions of a tile
+// are issued its registers take the same tile of the NEXT stage, so that all four fetches are on their way before
+// the pairs of the next stage are expanded into the A operand registers (the other wave of the SIMD multiplies
+// meanwhile): every fetch has the whole expansion to arrive.
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ void sp_stage(f32x4 (&acc)[4][4], SpW (&Wr)[4], SpA& A, f32x4& xn,
+                                         const u32x4* __restrict__ wnext, const float* knots_next, int nk,
+                                         const f32x4* __restrict__ xnext2, const JetScales& sc, int lane) {
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    sp_multiply(acc, A, Wr[n], n);
+    sp_load_w(Wr[n], wnext, n, lane);
+    PDEKAN_REGION_FENCE();
+  }
+  sp_expand<C1, ACT, GEN>(knots_next, nk, xn, sc, A);
+  xn = *xnext2;
+  PDEKAN_REGION_FENCE();
+}
+
+template <int C1, int ACT, bool GEN, bool LONGK>
+__device__ __forceinline__ void
+fwd_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+            const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
+            const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
+  constexpr int nk = C1 + 3, KP = layer_knot_pad(nk, GEN);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
+  if constexpr (GEN) {                       // [g_0 x3][the nk knots][g_last x4][1/h]
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  const JetScales sc = expanded_jet_scales(amax_in, max_inv_h(ginfo, I, lane));
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  __syncthreads();
+
+  const int oc = lane & 15, tb = lane >> 4;                // expansion: point oc of the wave, feature tb of the stage
+  const int o0 = blockIdx.y * 64;
+  const int nst = I / 4;
+  const u32x4* wbase = wsp + (size_t)blockIdx.y * nst * kSpStageVecs;
+  const float* kbase = sK + tb * KP + (GEN ? 3 : 0);
+  // A block walks tiles of 64 points (16 per wave), blockIdx.x, + gridDim.x, ...: the stages of a wave's tiles
+  // form one stream - the last stages of a tile expand the first pairs of the next tile and fetch its first B tiles
+  // (the same for every tile) and input jets, so that only the first tile of a wave starts cold.
+  auto row_of = [&](int64_t tile) {
+    int64_t prow = (tile * 4 + wave) * 16 + oc;
+    if (prow > N - 1) prow = N - 1;
+    return a + prow * I + tb;                              // + 4 per stage
+  };
+  int64_t tile = blockIdx.x;
+  if ((tile * 4 + wave) * 16 >= N) return;                 // wave-uniform; no barrier below
+  const f32x4* xrow = row_of(tile);
+
+  f32x4 acc[4][4], tot[LONGK ? 4 : 1][LONGK ? 4 : 1];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (LONGK) tot[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  f32x4 inv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[j] * sw);
+  f32x4 vmax = {0.f, 0.f, 0.f, 0.f};
+  // stage s is multiplied, then the pairs of stage s + 1 are expanded; the input jets of stage s + 2 are on their way
+  SpW Wr[4];
+  SpA A;
+  f32x4 xn;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) sp_load_w(Wr[n], wbase, n, lane);
+  sp_expand<C1, ACT, GEN>(kbase, nk, xrow[0], sc, A);
+  xn = xrow[4];                                            // (at least 2 stages: I is a multiple of 8)
+  for (;;) {
+    const int64_t P0 = (tile * 4 + wave) * 16;
+    const int64_t tnext = tile + gridDim.x;
+    const bool more = (tnext * 4 + wave) * 16 < N;
+    const f32x4* xrow_next = more ? row_of(tnext) : xrow;  // (past the last tile: any valid data, never multiplied)
+    for (int s = 0; s < nst; s += 2) {                     // (an even number of stages)
+      const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : s + 2 - nst, s3 = (s + 3 < nst) ? s + 3 : s + 3 - nst;
+      const f32x4* x2 = ((s + 2 < nst) ? xrow : xrow_next) + 4 * s2;
+      const f32x4* x3 = ((s + 3 < nst) ? xrow : xrow_next) + 4 * s3;
+      sp_stage<C1, ACT, GEN>(acc, Wr, A, xn, wbase + (size_t)s1 * kSpStageVecs, kbase + 4 * s1 * KP, nk, x2, sc, lane);
+      sp_stage<C1, ACT, GEN>(acc, Wr, A, xn, wbase + (size_t)s2 * kSpStageVecs, kbase + 4 * s2 * KP, nk, x3, sc, lane);
+      if constexpr (LONGK) {
+        if (((s + 2) % kFwdFlushStages) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { tot[j][n] += acc[j][n]; acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+      }
+    }
+    // D: row tile j = jet j of the wave's 16 points; this lane holds points 4 tb + i for output 16n + oc
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t p = P0 + 4 * tb + i;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        f32x4 v = {acc[0][n][i], acc[1][n][i], acc[2][n][i], acc[3][n][i]};
+        if constexpr (LONGK) v += (f32x4){tot[0][n][i], tot[1][n][i], tot[2][n][i], tot[3][n][i]};
+        v *= inv;
+        if (p < N) {
+          y[p * O + o0 + 16 * n + oc] = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(v[j]));
+        }
+      }
+    }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (LONGK) tot[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    tile = tnext;
+    xrow = xrow_next;
+  }
+  if (amax_out) publish_jet_max(vmax, amax_out, lane);
+}
+
+template <int C1, int ACT, bool LONGK>
+__global__ void __launch_bounds__(256, LONGK ? 1 : 2)
+fwd_sp_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                  const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
+                  const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
+  const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
+  if (cls == 1) fwd_sp_body<C1, ACT, false, LONGK>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax, amax_out);
+  else if (cls == 2) fwd_sp_body<C1, ACT, true, LONGK>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax, amax_out);
 }
 
 // ==========================================================================================================
@@ -2790,6 +3044,12 @@ bool f16_wide_forward12(const LayerView& L) {
   return L.G == 10 && !(off && off[0] == '1');
 }
 
+// 4-jet layers whose forward runs on the structured-sparsity instruction (fwd_sp_f16_kernel: its own forward image)
+static bool f16_sparse_forward(const LayerView& L) {
+  const char* off = getenv("PDEKAN_DISABLE_F16_SPARSE");  // A/B switch for tests and profiling
+  return L.G == 10 && !(off && off[0] == '1');
+}
+
 // jets12: the planes are for the 12-jet kernels
 void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st, bool jets12) {
   u32x4* f = reinterpret_cast<u32x4*>(wpl);
@@ -2799,7 +3059,8 @@ void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* 
   const int total = (L.O / 64) * ((L.I / 4) * (cp / 8) * 4 + (L.I / 8) * nrp) * 64;
   int blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (L.G == 10 && jets12 && f16_wide_forward12(L)) pack_wplanes16_kernel<14, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  if (L.G == 10 && !jets12 && f16_sparse_forward(L)) pack_wplanes16_kernel<14, false, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  else if (L.G == 10 && jets12 && f16_wide_forward12(L)) pack_wplanes16_kernel<14, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
   else if (L.G == 10) pack_wplanes16_kernel<14, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
   else pack_wplanes16_kernel<24, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
 }
@@ -2822,6 +3083,20 @@ static void fwd_f16_launch(const LayerView& L, const float* a, const float* wpl,
                          reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax, amax_out);
 }
 
+template <int C1, int ACT>
+static void fwd_sp_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
+                          const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
+  const bool longk = (L.I / 4) * 3 > kFwdChainMax;
+  auto k = longk ? fwd_sp_f16_kernel<C1, ACT, true> : fwd_sp_f16_kernel<C1, ACT, false>;
+  const size_t lds = (size_t)L.I * layer_knot_pad(C1 + 3, true) * 4;
+  // blocks walk the tiles of 64 points with a stride: four rounds of resident blocks at most (256 CUs x 2 blocks)
+  int64_t tiles = (N + 63) / 64;
+  const int64_t cap = 2048 / (L.O / 64);
+  dim3 g((unsigned)(tiles < cap ? tiles : cap), L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wpl),
+                         reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax, amax_out);
+}
+
 template <int C1>
 static void fwd_f16_variants(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
                              const unsigned* amax_in, const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
@@ -2832,7 +3107,10 @@ static void fwd_f16_variants(const LayerView& L, const float* a, const float* wp
 // one launch: a block takes the variant that matches the layer's knot rows (or returns at once)
 void launch_fwd_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
                     const unsigned* wmax, unsigned* amax_out, hipStream_t st) {
-  if (L.G == 10) fwd_f16_variants<14>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  if (f16_sparse_forward(L)) {
+    if (L.act == kActSiLU) fwd_sp_launch<14, kActSiLU>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+    else fwd_sp_launch<14, kActIdentity>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
+  } else if (L.G == 10) fwd_f16_variants<14>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
   else fwd_f16_variants<24>(L, a, wpl, y, N, amax_in, wmax, amax_out, st);
 }
 

@@ -137,6 +137,28 @@ def _run12(lay, xj, gy):
     return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in lay.parameters()]
 
 
+@pytest.mark.parametrize("I,O_,N,knots", [(64, 64, 70000, "default"), (8, 64, 5, "default"), (256, 256, 1030, "default"),
+                                          (128, 192, 4099, "jittered"), (24, 64, 640001, "default")])
+def test_forward_on_the_sparse_matrix_instruction_agrees_with_the_dense_one(I, O_, N, knots, monkeypatch):
+    """The grid-10 forward takes the 5 live columns of a feature as a 2:4 structured-sparse operand
+    (v_smfmac_f32_16x16x64_f16, operands straight from the expansion's registers, its own image of the W planes);
+    with PDEKAN_DISABLE_F16_SPARSE=1 the dense 16 x 16 x 32 kernel and its image run.  The products are the same,
+    the order of the sums is not.  Points outside the extended grid and in its first / last intervals (live columns
+    outside the layer's columns), 2 to 64 stages, the accumulator flush of wide layers, more tiles than blocks
+    (640001 points: blocks walk several tiles, the last one ragged); the backward kernels are the same either way."""
+    lay = _layer(I, O_, 10, knots, I + O_ + 7)
+    xj, gy = _jets(N, I, O_, N + 3)
+    a = _run(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16_SPARSE", "1")
+    b = _run(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16_SPARSE")
+    for j in range(4):
+        assert max_rel(a[0][..., j].cpu(), b[0][..., j].cpu()) <= 2e-6, ("y", j)
+    assert not torch.equal(a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+
+
 def _jets12(N, I, O_, seed, scale=None):
     g = torch.Generator().manual_seed(seed)
     s = torch.ones(12) if scale is None else torch.tensor(scale)
