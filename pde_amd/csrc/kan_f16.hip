@@ -2450,6 +2450,241 @@ fwd12w_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, c
   }
 }
 
+// ---- forward, 12 jets, on the structured-sparsity matrix instruction (see fwd_sp_f16_kernel for the operand layout;
+// the same image of the W planes).  A row tile is ONE slot of the wave's 16 points, so lane (p, f) of the expansion
+// holds the A operands of all 12 row tiles of its pair: 12 slots x 2 planes x 4 words.  Wave = 16 points x 12 slots x
+// 64 outputs = 48 accumulator tiles (192 registers), one wave per SIMD; every lane expands a pair of its own (the
+// dense kernels' 8-point tiles leave half of the lanes with copies).  A stage (4 features) is 144 matrix
+// instructions in 12 sub-steps of 12: slots (2u, 2u+1) against output tiles 0, 1 (u < 6), then against tiles 2, 3.
+// The A operands are rewritten in place: a pair of slots is cut for the NEXT stage one sub-step after its last
+// use (sub-steps 7 .. 11; slots 10, 11 in sub-step 0 of the next stage), the basis, activation and row coefficients
+// of the next stage's pair are evaluated under sub-steps 1 .. 6, the B tiles 0, 1 / 2, 3 are fetched for the next
+// stage as soon as their half of the stage is issued, the input jets three stages ahead.  Persistent blocks: the
+// stages of a wave's tiles form one stream, as in fwd_sp_f16_kernel.  No second register set for long sums:
+// layers with more than kFwdChainMax chained instructions per accumulator (I > 168) keep the dense kernel.
+struct SpA12 { u32x4 h[12], l[12]; };
+struct SpState12 { float b[4], d1[4], d2[4], f0, f1, f2; RowCoefs12 rc; };
+
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ unsigned sp_state12(const float* knots, int nk, const f32x4 (&x)[3], const SlotScales12& sc,
+                                               SpState12& st) {
+  constexpr int C = C1 - 1;
+  static_assert(C == 13, "the base column sits in group 1, slot 3");
+  const FeatGrid fg = {knots[0], knots[nk - 1], fabsf(knots[GEN ? nk + 4 : nk])};
+  Basis bs;
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
+  const Act av = eval_act(ACT, x[0][0]);
+  const int r = bs.c0 & 3, base4 = bs.c0 >> 2;
+  sp_rotate(bs.b, r); sp_rotate(bs.d1, r); sp_rotate(bs.d2, r);
+  unsigned idx = 0xCCCCu;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int slot = base4 + (g < r ? 1 : 0);
+    const bool ok = slot >= 0 && 4 * slot + g < C;
+    st.b[g] = ok ? bs.b[g] : 0.0f; st.d1[g] = ok ? bs.d1[g] : 0.0f; st.d2[g] = ok ? bs.d2[g] : 0.0f;
+    idx |= (unsigned)(slot & 3) << (4 * g);
+  }
+  st.f0 = av.f0; st.f1 = av.f1; st.f2 = av.f2;
+  st.rc = row_coefs12(x, sc);
+  return idx;
+}
+
+// slot J of the pair's A operands (J is a constant after unrolling): word g = (live column of group g, second element)
+__device__ __forceinline__ void sp_cut12(const SpState12& st, SpA12& A, const int J) {
+  const int q = J >> 2, r = J & 3;
+  auto val = [&](float b0, float b1, float b2) {
+    if (J == 0) return st.rc.s0 * b0;
+    float v = st.rc.be[q][r] * b1;
+    if (J == 7) v += st.rc.ga[1][3] * b2;
+    if (q == 2) v += st.rc.ga[2][r] * b2;
+    return v;
+  };
+  const float cb = val(st.f0, st.f1, st.f2);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float cg = val(st.b[g], st.d1[g], st.d2[g]);
+    unsigned h, l;
+    if (g == 1) {
+      split_pair16(cg, cb, h, l);
+    } else {
+      asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(cg));
+      l = 0u;
+      asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(cg));
+    }
+    A.h[J][g] = h;
+    A.l[J][g] = l;
+  }
+}
+
+// slots j0, j0 + 1 against output tiles n0, n0 + 1: 12 matrix instructions on 4 accumulators
+__device__ __forceinline__ void sp_multiply12(f32x4 (&acc)[12][4], const SpA12& A, unsigned idx, const SpW& W0, const SpW& W1,
+                                              const int j0, const int n0) {
+  const f16x16 Bh[2] = {sp_b16(W0.h[0], W0.h[1]), sp_b16(W1.h[0], W1.h[1])};
+  const f16x16 Bl[2] = {sp_b16(W0.l[0], W0.l[1]), sp_b16(W1.l[0], W1.l[1])};
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+      acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.l[j0 + jj]), Bh[nn],
+                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+      acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j0 + jj]), Bl[nn],
+                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+      acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j0 + jj]), Bh[nn],
+                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+}
+
+// One stage.  On entry: A = slots 0 .. 9 of this stage's pairs, st = the state they were cut from, idx = their
+// positions; xuse = the input jets of the next stage's pair.  On exit the same for the next stage, and xuse holds
+// the jets three stages on (the caller alternates two such buffers).
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ void sp12_stage(f32x4 (&acc)[12][4], SpW (&Wr)[4], SpA12& A, unsigned& idx, SpState12& st,
+                                           f32x4 (&xuse)[3], const u32x4* __restrict__ wnext, const float* knots_next,
+                                           int nk, const f32x4* __restrict__ xload, const SlotScales12& sc, int lane) {
+  sp_multiply12(acc, A, idx, Wr[0], Wr[1], 0, 0);
+  sp_cut12(st, A, 10);
+  sp_cut12(st, A, 11);
+  interleave<12, 3>();
+  PDEKAN_REGION_FENCE();
+#pragma unroll
+  for (int u = 1; u < 6; ++u) sp_multiply12(acc, A, idx, Wr[0], Wr[1], 2 * u, 0);
+  const unsigned idx_next = sp_state12<C1, ACT, GEN>(knots_next, nk, xuse, sc, st);
+  interleave<60, 3>();
+  PDEKAN_REGION_FENCE();
+  sp_load_w(Wr[0], wnext, 0, lane);
+  sp_load_w(Wr[1], wnext, 1, lane);
+  sp_multiply12(acc, A, idx, Wr[2], Wr[3], 0, 2);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) xuse[q] = xload[q];
+  interleave<12, 2>();
+  PDEKAN_REGION_FENCE();
+#pragma unroll
+  for (int u = 7; u < 12; ++u) {
+    sp_multiply12(acc, A, idx, Wr[2], Wr[3], 2 * (u - 6), 2);
+    sp_cut12(st, A, 2 * (u - 7));
+    sp_cut12(st, A, 2 * (u - 7) + 1);
+    interleave<12, 3>();
+    PDEKAN_REGION_FENCE();
+  }
+  sp_load_w(Wr[2], wnext, 2, lane);
+  sp_load_w(Wr[3], wnext, 3, lane);
+  idx = idx_next;
+}
+
+template <int C1, int ACT, bool GEN>
+__device__ __forceinline__ void
+fwd12_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+              const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
+              const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
+  constexpr int nk = C1 + 3, KP = layer_knot_pad(nk, GEN);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
+  if constexpr (GEN) {                       // [g_0 x3][the nk knots][g_last x4][1/h]
+    for (int idx = tid; idx < I * KP; idx += 256) {
+      const int f = idx / KP, k = idx - f * KP - 3;
+      sK[idx] = (k == nk + 4) ? ginfo[f] : grid[(size_t)f * nk + (k < 0 ? 0 : (k > nk - 1 ? nk - 1 : k))];
+    }
+  } else {
+    for (int idx = tid; idx < I * (nk + 1); idx += 256) {
+      const int f = idx / (nk + 1), k = idx - f * (nk + 1);
+      sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
+    }
+  }
+  const SlotScales12 sc = expanded_slot_scales12(amax_in, max_inv_h(ginfo, I, lane));
+  const float sw = pow2_scale(__uint_as_float(wmax[0]));
+  __syncthreads();
+
+  const int oc = lane & 15, tb = lane >> 4;                // expansion: point oc of the wave, feature tb of the stage
+  const int o0 = blockIdx.y * 64;
+  const int nst = I / 4;                                   // (at least 8: I is a multiple of 32)
+  const u32x4* wbase = wsp + (size_t)blockIdx.y * nst * kSpStageVecs;
+  const float* kbase = sK + tb * KP + (GEN ? 3 : 0);
+  auto row_of = [&](int64_t tile) {
+    int64_t prow = (tile * 4 + wave) * 16 + oc;
+    if (prow > N - 1) prow = N - 1;
+    return a + (prow * I + tb) * 3;                        // + 12 per stage
+  };
+  int64_t tile = blockIdx.x;
+  if ((tile * 4 + wave) * 16 >= N) return;                 // wave-uniform; no barrier below
+  const f32x4* xrow = row_of(tile);
+
+  f32x4 acc[12][4];
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  SpW Wr[4];
+  SpA12 A;
+  SpState12 st;
+  unsigned idx;
+  f32x4 xa[3], xb[3];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) sp_load_w(Wr[n], wbase, n, lane);
+  {
+    f32x4 x0[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { x0[q] = xrow[q]; xa[q] = xrow[12 + q]; xb[q] = xrow[24 + q]; }
+    idx = sp_state12<C1, ACT, GEN>(kbase, nk, x0, sc, st);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) sp_cut12(st, A, j);
+  }
+  for (;;) {
+    const int64_t P0 = (tile * 4 + wave) * 16;
+    const int64_t tnext = tile + gridDim.x;
+    const bool more = (tnext * 4 + wave) * 16 < N;
+    const f32x4* xrow_next = more ? row_of(tnext) : xrow;  // (past the last tile: any valid data, never multiplied)
+    for (int s = 0; s < nst; s += 2) {                     // (an even number of stages)
+      const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : s + 2 - nst;
+      const f32x4* x3 = ((s + 3 < nst) ? xrow + 12 * (s + 3) : xrow_next + 12 * (s + 3 - nst));
+      const f32x4* x4 = ((s + 4 < nst) ? xrow + 12 * (s + 4) : xrow_next + 12 * (s + 4 - nst));
+      sp12_stage<C1, ACT, GEN>(acc, Wr, A, idx, st, xa, wbase + (size_t)s1 * kSpStageVecs, kbase + 4 * s1 * KP, nk, x3, sc, lane);
+      sp12_stage<C1, ACT, GEN>(acc, Wr, A, idx, st, xb, wbase + (size_t)s2 * kSpStageVecs, kbase + 4 * s2 * KP, nk, x4, sc, lane);
+    }
+    // D: row tile j = slot j of the wave's 16 points; this lane holds points 4 tb + i for output 16n + oc
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      f32x4 inv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[4 * g + j] * sw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t p = P0 + 4 * tb + i;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const f32x4 v = {acc[4 * g][n][i], acc[4 * g + 1][n][i], acc[4 * g + 2][n][i], acc[4 * g + 3][n][i]};
+          if (p < N) y[(p * O + o0 + 16 * n + oc) * 3 + g] = v * inv;
+        }
+      }
+    }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile = tnext;
+    xrow = xrow_next;
+  }
+}
+
+template <int C1, int ACT>
+__global__ void __launch_bounds__(256, 1)
+fwd12_sp_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+                    const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
+                    const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
+  const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
+  if (cls == 1) fwd12_sp_body<C1, ACT, false>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax);
+  else if (cls == 2) fwd12_sp_body<C1, ACT, true>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax);
+}
+
 // ---- input-jet gradients, 12 jets: wave = 8 points x 3 groups = 6 row tiles of gY (A operands, in registers) against
 // the W planes of 64 outputs at a time, as in bwd_input_f16_kernel; a stage = 4 features = NB column tiles x 2
 // k-steps = 2*NB regions of 18 matrix instructions.  The stage's gE tile [8 points][4*CP columns][12 slots] is
@@ -3050,6 +3285,12 @@ static bool f16_sparse_forward(const LayerView& L) {
   return L.G == 10 && !(off && off[0] == '1');
 }
 
+// 12-jet layers whose forward runs on the structured-sparsity instruction (fwd12_sp_f16_kernel: the same image)
+static bool f16_sparse_forward12(const LayerView& L) {
+  const char* off = getenv("PDEKAN_DISABLE_F16_SPARSE");  // A/B switch for tests and profiling
+  return L.G == 10 && (L.I / 4) * 3 <= kFwdChainMax && !(off && off[0] == '1');
+}
+
 // jets12: the planes are for the 12-jet kernels
 void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* wmax, float* wpl, hipStream_t st, bool jets12) {
   u32x4* f = reinterpret_cast<u32x4*>(wpl);
@@ -3059,7 +3300,7 @@ void launch_pack_wplanes16(const LayerView& L, const float* wp, const unsigned* 
   const int total = (L.O / 64) * ((L.I / 4) * (cp / 8) * 4 + (L.I / 8) * nrp) * 64;
   int blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (L.G == 10 && !jets12 && f16_sparse_forward(L)) pack_wplanes16_kernel<14, false, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
+  if (L.G == 10 && (jets12 ? f16_sparse_forward12(L) : f16_sparse_forward(L))) pack_wplanes16_kernel<14, false, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
   else if (L.G == 10 && jets12 && f16_wide_forward12(L)) pack_wplanes16_kernel<14, true><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
   else if (L.G == 10) pack_wplanes16_kernel<14, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
   else pack_wplanes16_kernel<24, false><<<blocks, 256, 0, st>>>(wp, wmax, f, b, L.I, L.O);
@@ -3126,9 +3367,27 @@ static void fwd12_launch(const LayerView& L, const float* a, const float* wpl, f
                          reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax);
 }
 
+template <int ACT>
+static void fwd12_sp_launch(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N,
+                            const unsigned* amax_in, const unsigned* wmax, hipStream_t st) {
+  auto k = fwd12_sp_f16_kernel<14, ACT>;
+  const size_t lds = (size_t)L.I * layer_knot_pad(14 + 3, true) * 4;
+  // blocks walk the tiles of 64 points with a stride: four rounds of resident blocks at most (256 CUs x 1 block)
+  int64_t tiles = (N + 63) / 64;
+  const int64_t cap = 1024 / (L.O / 64);
+  dim3 g((unsigned)(tiles < cap ? tiles : cap), L.O / 64);
+  k<<<g, 256, lds, st>>>(reinterpret_cast<const f32x4*>(a), L.grid, L.ginfo, reinterpret_cast<const u32x4*>(wpl),
+                         reinterpret_cast<f32x4*>(y), N, L.I, L.O, amax_in, wmax);
+}
+
 // 12-jet forward (f16_jets12_eligible layers): amax_in = per-slot maxima of a (12 words).  N must be a multiple of 8.
 void launch_fwd12_f16(const LayerView& L, const float* a, const float* wpl, float* y, int64_t N, const unsigned* amax_in,
                       const unsigned* wmax, hipStream_t st) {
+  if (f16_sparse_forward12(L)) {
+    if (L.act == kActSiLU) fwd12_sp_launch<kActSiLU>(L, a, wpl, y, N, amax_in, wmax, st);
+    else fwd12_sp_launch<kActIdentity>(L, a, wpl, y, N, amax_in, wmax, st);
+    return;
+  }
   if (L.act == kActSiLU) {
     fwd12_launch<kActSiLU, false>(L, a, wpl, y, N, amax_in, wmax, st);
     fwd12_launch<kActSiLU, true>(L, a, wpl, y, N, amax_in, wmax, st);

@@ -194,10 +194,33 @@ def test_12_jet_forward_on_wide_tiles_agrees_with_the_narrow_tiles(I, O_, N, kno
     (the products are the same, the order of the sums is not); the backward kernels are the same either way."""
     lay = _layer(I, O_, 10, knots, I + O_ + 3)
     xj, gy = _jets12(N, I, O_, N + 2)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16_SPARSE", "1")      # (layers this narrow would take the sparse-operand kernel)
     a = _run12(lay, xj, gy)
     monkeypatch.setenv("PDEKAN_DISABLE_F16_WIDE", "1")
     b = _run12(lay, xj, gy)
     monkeypatch.delenv("PDEKAN_DISABLE_F16_WIDE")
+    monkeypatch.delenv("PDEKAN_DISABLE_F16_SPARSE")
+    for j in range(12):
+        assert max_rel(a[0][..., j].cpu(), b[0][..., j].cpu()) <= 2e-6, ("y", j)
+    assert not torch.equal(a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("I,O_,N,knots", [(128, 128, 70000, "default"), (32, 64, 8, "default"), (160, 256, 1031, "jittered"),
+                                          (64, 64, 140008, "default")])
+def test_12_jet_forward_on_the_sparse_matrix_instruction_agrees_with_the_dense_one(I, O_, N, knots, monkeypatch):
+    """The 12-jet forward of layers up to 160 inputs takes the live columns as a 2:4 structured-sparse operand (a row
+    tile = one slot of 16 points, operands rewritten in place from the expansion's registers); with
+    PDEKAN_DISABLE_F16_SPARSE=1 the dense 32 x 32 x 16 kernel and its image run.  Same products, another order of the
+    sums.  Points outside the extended grid, 8 to 40 stages, ragged last tiles, more tiles than blocks (140008
+    points: blocks walk several tiles); the backward kernels are the same either way."""
+    lay = _layer(I, O_, 10, knots, I + O_ + 5)
+    xj, gy = _jets12(N, I, O_, N + 4)
+    a = _run12(lay, xj, gy)
+    monkeypatch.setenv("PDEKAN_DISABLE_F16_SPARSE", "1")
+    b = _run12(lay, xj, gy)
+    monkeypatch.delenv("PDEKAN_DISABLE_F16_SPARSE")
     for j in range(12):
         assert max_rel(a[0][..., j].cpu(), b[0][..., j].cpu()) <= 2e-6, ("y", j)
     assert not torch.equal(a[0], b[0])
