@@ -721,9 +721,9 @@ __device__ __forceinline__ void sp_expand(const float* knots, int nk, f32x4 jet,
       unsigned h, l;
       if (g == 1) {
         split_pair16(cg[j], cb[j], h, l);
-      } else {                                 // (x, 0): the high halves of both planes stay zero
-        asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(cg[j]));
-        l = 0u;
+      } else {                                 // (x, 0): the high half of the low plane's word is zero since the kernel's
+        asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(cg[j]));                       // start and is never written
+        l = out.l[j][g];
         asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(cg[j]));
       }
       out.h[j][g] = h;
@@ -829,6 +829,8 @@ fwd_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const f
   // stage s is multiplied, then the pairs of stage s + 1 are expanded; the input jets of stage s + 2 are on their way
   SpW Wr[4];
   SpA A;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) A.l[j] = (u32x4){0u, 0u, 0u, 0u};     // (sp_expand keeps the high halves)
   f32x4 xn;
 #pragma unroll
   for (int n = 0; n < 4; ++n) sp_load_w(Wr[n], wbase, n, lane);
@@ -2463,18 +2465,26 @@ fwd12w_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid, c
 // stages of a wave's tiles form one stream, as in fwd_sp_f16_kernel.  No second register set for long sums:
 // layers with more than kFwdChainMax chained instructions per accumulator (I > 168) keep the dense kernel.
 struct SpA12 { u32x4 h[12], l[12]; };
-struct SpState12 { float b[4], d1[4], d2[4], f0, f1, f2; RowCoefs12 rc; };
+
+// one word of each plane for (x, 0); l comes in with its high half zero and keeps it
+__device__ __forceinline__ void split_single16(float x, unsigned& h, unsigned& l) {
+  asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(x));
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x));
+}
+
+// basis and activation of a pair in group order (the live column of group g; zero where that column is not one of
+// the layer's) and the positions of the live columns inside their groups
+struct SpPair { float b[4], d1[4], d2[4], f0, f1, f2; };
 
 template <int C1, int ACT, bool GEN>
-__device__ __forceinline__ unsigned sp_state12(const float* knots, int nk, const f32x4 (&x)[3], const SlotScales12& sc,
-                                               SpState12& st) {
+__device__ __forceinline__ unsigned sp_pair(const float* knots, int nk, float x, SpPair& out) {
   constexpr int C = C1 - 1;
   static_assert(C == 13, "the base column sits in group 1, slot 3");
   const FeatGrid fg = {knots[0], knots[nk - 1], fabsf(knots[GEN ? nk + 4 : nk])};
   Basis bs;
-  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
-  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, x[0][0], bs);
-  const Act av = eval_act(ACT, x[0][0]);
+  if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, x, bs);
+  else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, x, bs);
+  const Act av = eval_act(ACT, x);
   const int r = bs.c0 & 3, base4 = bs.c0 >> 2;
   sp_rotate(bs.b, r); sp_rotate(bs.d1, r); sp_rotate(bs.d2, r);
   unsigned idx = 0xCCCCu;
@@ -2482,109 +2492,127 @@ __device__ __forceinline__ unsigned sp_state12(const float* knots, int nk, const
   for (int g = 0; g < 4; ++g) {
     const int slot = base4 + (g < r ? 1 : 0);
     const bool ok = slot >= 0 && 4 * slot + g < C;
-    st.b[g] = ok ? bs.b[g] : 0.0f; st.d1[g] = ok ? bs.d1[g] : 0.0f; st.d2[g] = ok ? bs.d2[g] : 0.0f;
+    out.b[g] = ok ? bs.b[g] : 0.0f; out.d1[g] = ok ? bs.d1[g] : 0.0f; out.d2[g] = ok ? bs.d2[g] : 0.0f;
     idx |= (unsigned)(slot & 3) << (4 * g);
   }
-  st.f0 = av.f0; st.f1 = av.f1; st.f2 = av.f2;
-  st.rc = row_coefs12(x, sc);
+  out.f0 = av.f0; out.f1 = av.f1; out.f2 = av.f2;
   return idx;
 }
 
-// slot J of the pair's A operands (J is a constant after unrolling): word g = (live column of group g, second element)
-__device__ __forceinline__ void sp_cut12(const SpState12& st, SpA12& A, const int J) {
-  const int q = J >> 2, r = J & 3;
-  auto val = [&](float b0, float b1, float b2) {
-    if (J == 0) return st.rc.s0 * b0;
-    float v = st.rc.be[q][r] * b1;
-    if (J == 7) v += st.rc.ga[1][3] * b2;
-    if (q == 2) v += st.rc.ga[2][r] * b2;
-    return v;
-  };
-  const float cb = val(st.f0, st.f1, st.f2);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float cg = val(st.b[g], st.d1[g], st.d2[g]);
-    unsigned h, l;
-    if (g == 1) {
-      split_pair16(cg, cb, h, l);
-    } else {
-      asm("v_cvt_pk_f16_f32 %0, %1, 0" : "=v"(h) : "v"(cg));
-      l = 0u;
-      asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(cg));
-    }
-    A.h[J][g] = h;
-    A.l[J][g] = l;
+// The 12 row tiles of a wave are the 12 slots of the jets of 16 points.  (The 4 jets of 3 x 16 points on the same
+// frame - the B operands fetched once for three times the points - take the time of fwd_sp_f16_kernel: what bounds
+// both is the vector work per pair, which one wave per SIMD hides no better than two.)
+template <int C1, int ACT, bool GEN>
+struct SpRows12 {
+  using Scales = SlotScales12;
+  static constexpr int NIDX = 1;                           // row tiles j share the positions idx[j * NIDX / 12]
+  static constexpr int POINTS = 16, VECS = 3;              // points per wave tile, f32x4 per (point, feature)
+  struct State { SpPair pr; RowCoefs12 rc; };
+  static __device__ __forceinline__ Scales scales(const unsigned* amax_in, float inv_h_max) { return expanded_slot_scales12(amax_in, inv_h_max); }
+  static __device__ __forceinline__ float slot_scale(const Scales& sc, int j) { return sc.s[j]; }
+  // x: the 12 jets of the lane's pair
+  static __device__ __forceinline__ void state(const float* knots, int nk, const f32x4 (&x)[3], const Scales& sc, State& st,
+                                               unsigned (&idx)[1]) {
+    idx[0] = sp_pair<C1, ACT, GEN>(knots, nk, x[0][0], st.pr);
+    st.rc = row_coefs12(x, sc);
   }
-}
+  // slot J of the pair's A operands (J is a constant after unrolling): word g = (live column of group g, second element)
+  static __device__ __forceinline__ void cut(const State& st, SpA12& A, const int J) {
+    const int q = J >> 2, r = J & 3;
+    auto val = [&](float b0, float b1, float b2) {
+      if (J == 0) return st.rc.s0 * b0;
+      float v = st.rc.be[q][r] * b1;
+      if (J == 7) v += st.rc.ga[1][3] * b2;
+      if (q == 2) v += st.rc.ga[2][r] * b2;
+      return v;
+    };
+    const float cb = val(st.pr.f0, st.pr.f1, st.pr.f2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float cg = val(st.pr.b[g], st.pr.d1[g], st.pr.d2[g]);
+      unsigned h, l = A.l[J][g];               // (groups 0, 2, 3: high half zero since the kernel's start)
+      if (g == 1) split_pair16(cg, cb, h, l); else split_single16(cg, h, l);
+      A.h[J][g] = h;
+      A.l[J][g] = l;
+    }
+  }
+};
 
-// slots j0, j0 + 1 against output tiles n0, n0 + 1: 12 matrix instructions on 4 accumulators
-__device__ __forceinline__ void sp_multiply12(f32x4 (&acc)[12][4], const SpA12& A, unsigned idx, const SpW& W0, const SpW& W1,
-                                              const int j0, const int n0) {
+// row tiles j0, j0 + 1 against output tiles n0, n0 + 1: 12 matrix instructions on 4 accumulators
+template <int NIDX>
+__device__ __forceinline__ void sp_multiply12(f32x4 (&acc)[12][4], const SpA12& A, const unsigned (&idx)[NIDX], const SpW& W0,
+                                              const SpW& W1, const int j0, const int n0) {
   const f16x16 Bh[2] = {sp_b16(W0.h[0], W0.h[1]), sp_b16(W1.h[0], W1.h[1])};
   const f16x16 Bl[2] = {sp_b16(W0.l[0], W0.l[1]), sp_b16(W1.l[0], W1.l[1])};
+  const int ix = (int)idx[j0 * NIDX / 12];                 // (j0 is even: both row tiles have the same positions)
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
       acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.l[j0 + jj]), Bh[nn],
-                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+                                                                       acc[j0 + jj][n0 + nn], ix, 0, 0);
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
       acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j0 + jj]), Bl[nn],
-                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+                                                                       acc[j0 + jj][n0 + nn], ix, 0, 0);
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
       acc[j0 + jj][n0 + nn] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(__builtin_bit_cast(f16x8, A.h[j0 + jj]), Bh[nn],
-                                                                       acc[j0 + jj][n0 + nn], (int)idx, 0, 0);
+                                                                       acc[j0 + jj][n0 + nn], ix, 0, 0);
 }
 
-// One stage.  On entry: A = slots 0 .. 9 of this stage's pairs, st = the state they were cut from, idx = their
-// positions; xuse = the input jets of the next stage's pair.  On exit the same for the next stage, and xuse holds
+// One stage.  On entry: A = row tiles 0 .. 9 of this stage's pairs, st = the state they were cut from, idx = their
+// positions; xuse = the input jets of the next stage's pairs.  On exit the same for the next stage, and xuse holds
 // the jets three stages on (the caller alternates two such buffers).
-template <int C1, int ACT, bool GEN>
-__device__ __forceinline__ void sp12_stage(f32x4 (&acc)[12][4], SpW (&Wr)[4], SpA12& A, unsigned& idx, SpState12& st,
-                                           f32x4 (&xuse)[3], const u32x4* __restrict__ wnext, const float* knots_next,
-                                           int nk, const f32x4* __restrict__ xload, const SlotScales12& sc, int lane) {
-  sp_multiply12(acc, A, idx, Wr[0], Wr[1], 0, 0);
-  sp_cut12(st, A, 10);
-  sp_cut12(st, A, 11);
+template <class M>
+__device__ __forceinline__ void sp12_stage(f32x4 (&acc)[12][4], SpW (&Wr)[4], SpA12& A, unsigned (&idx)[M::NIDX],
+                                           typename M::State& st, f32x4 (&xuse)[3], const u32x4* __restrict__ wnext,
+                                           const float* knots_next, int nk, const f32x4* (&xload)[3],
+                                           const typename M::Scales& sc, int lane) {
+  sp_multiply12<M::NIDX>(acc, A, idx, Wr[0], Wr[1], 0, 0);
+  M::cut(st, A, 10);
+  M::cut(st, A, 11);
   interleave<12, 3>();
   PDEKAN_REGION_FENCE();
 #pragma unroll
-  for (int u = 1; u < 6; ++u) sp_multiply12(acc, A, idx, Wr[0], Wr[1], 2 * u, 0);
-  const unsigned idx_next = sp_state12<C1, ACT, GEN>(knots_next, nk, xuse, sc, st);
-  interleave<60, 3>();
+  for (int u = 1; u < 6; ++u) sp_multiply12<M::NIDX>(acc, A, idx, Wr[0], Wr[1], 2 * u, 0);
+  unsigned idx_next[M::NIDX];
+  M::state(knots_next, nk, xuse, sc, st, idx_next);
+  interleave<60, M::NIDX == 1 ? 3 : 6>();
   PDEKAN_REGION_FENCE();
   sp_load_w(Wr[0], wnext, 0, lane);
   sp_load_w(Wr[1], wnext, 1, lane);
-  sp_multiply12(acc, A, idx, Wr[2], Wr[3], 0, 2);
+  sp_multiply12<M::NIDX>(acc, A, idx, Wr[2], Wr[3], 0, 2);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) xuse[q] = xload[q];
+  for (int q = 0; q < 3; ++q) xuse[q] = *xload[q];
   interleave<12, 2>();
   PDEKAN_REGION_FENCE();
+  // (the row tiles cut below belong to the next stage: idx keeps this stage's positions until the stage is issued)
 #pragma unroll
   for (int u = 7; u < 12; ++u) {
-    sp_multiply12(acc, A, idx, Wr[2], Wr[3], 2 * (u - 6), 2);
-    sp_cut12(st, A, 2 * (u - 7));
-    sp_cut12(st, A, 2 * (u - 7) + 1);
+    sp_multiply12<M::NIDX>(acc, A, idx, Wr[2], Wr[3], 2 * (u - 6), 2);
+    M::cut(st, A, 2 * (u - 7));
+    M::cut(st, A, 2 * (u - 7) + 1);
     interleave<12, 3>();
     PDEKAN_REGION_FENCE();
   }
   sp_load_w(Wr[2], wnext, 2, lane);
   sp_load_w(Wr[3], wnext, 3, lane);
-  idx = idx_next;
+#pragma unroll
+  for (int t = 0; t < M::NIDX; ++t) idx[t] = idx_next[t];
 }
 
-template <int C1, int ACT, bool GEN>
+template <class M, int C1, bool GEN>
 __device__ __forceinline__ void
-fwd12_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
+fwd_sp12_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const float* __restrict__ ginfo,
               const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
-              const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
+              const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax, unsigned* __restrict__ amax_out) {
   constexpr int nk = C1 + 3, KP = layer_knot_pad(nk, GEN);
+  constexpr int PTS = M::POINTS, V = M::VECS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   float* sK = reinterpret_cast<float*>(smem);                               // [I][KP], shared by the block
@@ -2599,69 +2627,89 @@ fwd12_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const
       sK[f * KP + k] = (k < nk) ? grid[(size_t)f * nk + k] : ginfo[f];
     }
   }
-  const SlotScales12 sc = expanded_slot_scales12(amax_in, max_inv_h(ginfo, I, lane));
+  const typename M::Scales sc = M::scales(amax_in, max_inv_h(ginfo, I, lane));
   const float sw = pow2_scale(__uint_as_float(wmax[0]));
   __syncthreads();
 
-  const int oc = lane & 15, tb = lane >> 4;                // expansion: point oc of the wave, feature tb of the stage
+  const int oc = lane & 15, tb = lane >> 4;                // expansion: point oc of a 16-point tile, feature tb of the stage
   const int o0 = blockIdx.y * 64;
-  const int nst = I / 4;                                   // (at least 8: I is a multiple of 32)
+  const int nst = I / 4;                                   // (at least 4, and even)
   const u32x4* wbase = wsp + (size_t)blockIdx.y * nst * kSpStageVecs;
   const float* kbase = sK + tb * KP + (GEN ? 3 : 0);
-  auto row_of = [&](int64_t tile) {
-    int64_t prow = (tile * 4 + wave) * 16 + oc;
-    if (prow > N - 1) prow = N - 1;
-    return a + (prow * I + tb) * 3;                        // + 12 per stage
+  // the lane's 3 vectors of a stage: the 12 jets of its pair, or the 4 jets of its feature at three points
+  struct Rows { const f32x4* r[3]; };
+  auto rows_of = [&](int64_t tile) {
+    Rows R;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      int64_t prow = (tile * 4 + wave) * PTS + (V == 3 ? 0 : 16 * q) + oc;
+      if (prow > N - 1) prow = N - 1;
+      R.r[q] = a + (prow * I + tb) * V + (V == 3 ? q : 0);   // + 4 V per stage
+    }
+    return R;
   };
   int64_t tile = blockIdx.x;
-  if ((tile * 4 + wave) * 16 >= N) return;                 // wave-uniform; no barrier below
-  const f32x4* xrow = row_of(tile);
+  if ((tile * 4 + wave) * PTS >= N) return;                // wave-uniform; no barrier below
+  Rows xrow = rows_of(tile);
 
   f32x4 acc[12][4];
 #pragma unroll
   for (int j = 0; j < 12; ++j)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 vmax = {0.f, 0.f, 0.f, 0.f};
   SpW Wr[4];
   SpA12 A;
-  SpState12 st;
-  unsigned idx;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) A.l[j] = (u32x4){0u, 0u, 0u, 0u};    // (M::cut keeps the high halves)
+  typename M::State st;
+  unsigned idx[M::NIDX];
   f32x4 xa[3], xb[3];
 #pragma unroll
   for (int n = 0; n < 4; ++n) sp_load_w(Wr[n], wbase, n, lane);
   {
     f32x4 x0[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { x0[q] = xrow[q]; xa[q] = xrow[12 + q]; xb[q] = xrow[24 + q]; }
-    idx = sp_state12<C1, ACT, GEN>(kbase, nk, x0, sc, st);
+    for (int q = 0; q < 3; ++q) { x0[q] = xrow.r[q][0]; xa[q] = xrow.r[q][4 * V]; xb[q] = xrow.r[q][8 * V]; }
+    M::state(kbase, nk, x0, sc, st, idx);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) sp_cut12(st, A, j);
+    for (int j = 0; j < 10; ++j) M::cut(st, A, j);
   }
   for (;;) {
-    const int64_t P0 = (tile * 4 + wave) * 16;
+    const int64_t P0 = (tile * 4 + wave) * PTS;
     const int64_t tnext = tile + gridDim.x;
-    const bool more = (tnext * 4 + wave) * 16 < N;
-    const f32x4* xrow_next = more ? row_of(tnext) : xrow;  // (past the last tile: any valid data, never multiplied)
+    const bool more = (tnext * 4 + wave) * PTS < N;
+    const Rows xrow_next = more ? rows_of(tnext) : xrow;   // (past the last tile: any valid data, never multiplied)
     for (int s = 0; s < nst; s += 2) {                     // (an even number of stages)
       const int s1 = s + 1, s2 = (s + 2 < nst) ? s + 2 : s + 2 - nst;
-      const f32x4* x3 = ((s + 3 < nst) ? xrow + 12 * (s + 3) : xrow_next + 12 * (s + 3 - nst));
-      const f32x4* x4 = ((s + 4 < nst) ? xrow + 12 * (s + 4) : xrow_next + 12 * (s + 4 - nst));
-      sp12_stage<C1, ACT, GEN>(acc, Wr, A, idx, st, xa, wbase + (size_t)s1 * kSpStageVecs, kbase + 4 * s1 * KP, nk, x3, sc, lane);
-      sp12_stage<C1, ACT, GEN>(acc, Wr, A, idx, st, xb, wbase + (size_t)s2 * kSpStageVecs, kbase + 4 * s2 * KP, nk, x4, sc, lane);
+      const f32x4 *x3[3], *x4[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        x3[q] = (s + 3 < nst) ? xrow.r[q] + 4 * V * (s + 3) : xrow_next.r[q] + 4 * V * (s + 3 - nst);
+        x4[q] = (s + 4 < nst) ? xrow.r[q] + 4 * V * (s + 4) : xrow_next.r[q] + 4 * V * (s + 4 - nst);
+      }
+      sp12_stage<M>(acc, Wr, A, idx, st, xa, wbase + (size_t)s1 * kSpStageVecs, kbase + 4 * s1 * KP, nk, x3, sc, lane);
+      sp12_stage<M>(acc, Wr, A, idx, st, xb, wbase + (size_t)s2 * kSpStageVecs, kbase + 4 * s2 * KP, nk, x4, sc, lane);
     }
-    // D: row tile j = slot j of the wave's 16 points; this lane holds points 4 tb + i for output 16n + oc
+    // D: this lane holds rows 4 tb + i of every row tile for output 16n + oc
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       f32x4 inv;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(sc.s[4 * g + j] * sw);
+      for (int j = 0; j < 4; ++j) inv[j] = rcp_pow2(M::slot_scale(sc, 4 * g + j) * sw);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int64_t p = P0 + 4 * tb + i;
+        const int64_t p = P0 + (V == 3 ? 0 : 16 * g) + 4 * tb + i;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          const f32x4 v = {acc[4 * g][n][i], acc[4 * g + 1][n][i], acc[4 * g + 2][n][i], acc[4 * g + 3][n][i]};
-          if (p < N) y[(p * O + o0 + 16 * n + oc) * 3 + g] = v * inv;
+          const f32x4 v = (f32x4){acc[4 * g][n][i], acc[4 * g + 1][n][i], acc[4 * g + 2][n][i], acc[4 * g + 3][n][i]} * inv;
+          if (p < N) {
+            y[(p * O + o0 + 16 * n + oc) * V + (V == 3 ? g : 0)] = v;
+            if constexpr (V == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) vmax[j] = fmaxf(vmax[j], fabsf(v[j]));
+            }
+          }
         }
       }
     }
@@ -2673,6 +2721,9 @@ fwd12_sp_body(const f32x4* __restrict__ a, const float* __restrict__ grid, const
     tile = tnext;
     xrow = xrow_next;
   }
+  if constexpr (V == 1) {
+    if (amax_out) publish_jet_max(vmax, amax_out, lane);
+  }
 }
 
 template <int C1, int ACT>
@@ -2681,8 +2732,8 @@ fwd12_sp_f16_kernel(const f32x4* __restrict__ a, const float* __restrict__ grid,
                     const u32x4* __restrict__ wsp, f32x4* __restrict__ y, int64_t N, int I, int O,
                     const unsigned* __restrict__ amax_in, const unsigned* __restrict__ wmax) {
   const int cls = layer_knot_class(ginfo, I, threadIdx.x & 63);
-  if (cls == 1) fwd12_sp_body<C1, ACT, false>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax);
-  else if (cls == 2) fwd12_sp_body<C1, ACT, true>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax);
+  if (cls == 1) fwd_sp12_body<SpRows12<C1, ACT, false>, C1, false>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax, nullptr);
+  else if (cls == 2) fwd_sp12_body<SpRows12<C1, ACT, true>, C1, true>(a, grid, ginfo, wsp, y, N, I, O, amax_in, wmax, nullptr);
 }
 
 // ---- input-jet gradients, 12 jets: wave = 8 points x 3 groups = 6 row tiles of gY (A operands, in registers) against
