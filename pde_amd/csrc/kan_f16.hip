@@ -695,16 +695,20 @@ __device__ __forceinline__ void sp_expand(const float* knots, int nk, f32x4 jet,
   if constexpr (GEN) eval_basis_near_uniform(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
   else eval_basis_uniform_by_quotient(knots, nk, fg.g0, fg.glast, fg.inv_h, jet[0], bs);
   const Act av = eval_act(ACT, jet[0]);
-  // group g holds the live column c_g = 4 slot_g + g, slot_g = (c0 >> 2) + (g < (c0 & 3)); columns outside 0 .. C-1
-  // count for nothing (their positions may be another column's: zeroed here, not by zero weights)
+  // group g holds the live column c_g = 4 slot_g + g, slot_g = (c0 >> 2) + (g < (c0 & 3))
   const int r = bs.c0 & 3, base4 = bs.c0 >> 2;
   sp_rotate(bs.b, r); sp_rotate(bs.d1, r); sp_rotate(bs.d2, r);
+  // A live column outside 0 .. C-1 is column -3 .. -1 or 13 .. 15: never one of group 0; in groups 2 and 3 its
+  // position, slot & 3 = 3, is that of the padding columns 14 and 15, whose weights are zero; in group 1 it is the base
+  // column's position: only there the values are zeroed.
   unsigned idx = 0xCCCCu;                                  // the second element of every pair: position 3
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int slot = base4 + (g < r ? 1 : 0);
-    const bool ok = slot >= 0 && 4 * slot + g < C;
-    bs.b[g] = ok ? bs.b[g] : 0.0f; bs.d1[g] = ok ? bs.d1[g] : 0.0f; bs.d2[g] = ok ? bs.d2[g] : 0.0f;
+    if (g == 1) {
+      const bool ok = slot >= 0 && 4 * slot + g < C;
+      bs.b[g] = ok ? bs.b[g] : 0.0f; bs.d1[g] = ok ? bs.d1[g] : 0.0f; bs.d2[g] = ok ? bs.d2[g] : 0.0f;
+    }
     idx |= (unsigned)(slot & 3) << (4 * g);
   }
   out.idx = idx;
@@ -2487,11 +2491,11 @@ __device__ __forceinline__ unsigned sp_pair(const float* knots, int nk, float x,
   const Act av = eval_act(ACT, x);
   const int r = bs.c0 & 3, base4 = bs.c0 >> 2;
   sp_rotate(bs.b, r); sp_rotate(bs.d1, r); sp_rotate(bs.d2, r);
-  unsigned idx = 0xCCCCu;
+  unsigned idx = 0xCCCCu;                                  // (see sp_expand: only group 1 needs its values zeroed)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int slot = base4 + (g < r ? 1 : 0);
-    const bool ok = slot >= 0 && 4 * slot + g < C;
+    const bool ok = g != 1 || (slot >= 0 && 4 * slot + g < C);
     out.b[g] = ok ? bs.b[g] : 0.0f; out.d1[g] = ok ? bs.d1[g] : 0.0f; out.d2[g] = ok ? bs.d2[g] : 0.0f;
     idx |= (unsigned)(slot & 3) << (4 * g);
   }
